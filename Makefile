@@ -1,0 +1,30 @@
+# Builds libmnt753_hip.so (HIP kernels + C ABI) for gfx950, the CPU oracle, and (when /root/reference is
+# present) the reference build used to pin the oracle.  `make -j8` from the repo root.
+PKG   := snark-challenge-prover-reference_amd
+CSRC  := $(PKG)/csrc
+BUILD := build
+HIPCC ?= hipcc
+HIPFLAGS := -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-result
+LIB   := $(PKG)/libmnt753_hip.so
+
+HIP_SRCS := mnt753_core.hip mnt753_msm.hip msm_inst_mnt4g1.hip msm_inst_mnt4g2.hip msm_inst_mnt6g1.hip msm_inst_mnt6g2.hip mnt753_fft.hip
+HIP_OBJS := $(addprefix $(BUILD)/,$(HIP_SRCS:.hip=.o))
+HDRS := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.cuh $(CSRC)/*.h include/*.h)
+
+all: $(LIB) oracle
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(BUILD) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,128 @@
+/* mnt753_hip.h -- C ABI of libmnt753_hip.so: the MI355X (gfx950) implementation of the Groth16 prover
+ * hot path of MinaProtocol/snark-challenge-prover-reference (MSM over G1/G2 and radix-2 FFT over Fr of
+ * MNT4753 / MNT6753).
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  The C++ class pair mnt4753_hip / mnt6753_hip in
+ * include/prover_hip_functions.hpp mirrors libsnark/prover_reference_include/prover_reference_functions.hpp
+ * member for member on top of this ABI; INTEGRATION.md shows the reference-side binding.
+ *
+ * Data formats (identical to the reference's files, libsnark/serialization.hpp:22-121):
+ *   Fr / Fq element : 12 little-endian uint64 limbs, Montgomery form with R = 2^768, fully reduced.
+ *   G1 affine       : x | y                      (24 u64);  y == 0 encodes the identity.
+ *   G2 affine       : x.c0 | x.c1 [| x.c2] | y.c0 | y.c1 [| y.c2]   (48 u64 MNT4753, 72 u64 MNT6753).
+ *   projective      : X | Y | Z  (homogeneous projective, identity = (0 : 1 : 0)) -- the in-memory form
+ *                     of libff::mnt4753_G1 (depends/libff/libff/algebra/curves/mnt753/mnt4753/mnt4753_g1.hpp).
+ *
+ * Conventions: every function returns 0 on success and a negative MNT753_E* code on failure;
+ * mnt753_last_error() returns a message for the calling thread's last failure.  Pointers named dev_*
+ * are HIP device pointers (e.g. torch tensor.data_ptr(), or mnt753_dev_alloc); all others are host
+ * pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).  One context per
+ * process; calls are serialised by the caller (same threading contract as the reference wrapper).
+ * There is NO CPU fallback: without a HIP device every compute entry point returns MNT753_ENODEV.
+ */
+#ifndef MNT753_HIP_H
+#define MNT753_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNT753_CURVE_MNT4753 0
+#define MNT753_CURVE_MNT6753 1
+#define MNT753_G1 1
+#define MNT753_G2 2
+
+#define MNT753_OK 0
+#define MNT753_EINVAL (-1)   /* bad argument (null pointer, size, curve / group id) */
+#define MNT753_ENODEV (-2)   /* no HIP device / library not initialised */
+#define MNT753_EHIP (-3)     /* a HIP runtime call failed */
+#define MNT753_ENOMEM (-4)   /* device or host allocation failed */
+#define MNT753_EDOMAIN (-5)  /* FFT size is not a supported power of two for this field */
+
+/* FFT kinds: libfqfft basic_radix2_domain::{FFT,iFFT,cosetFFT,icosetFFT}
+ * (depends/libfqfft/libfqfft/evaluation_domain/domains/basic_radix2_domain.tcc:62-96);
+ * the coset shift is Fr::multiplicative_generator as in libsnark/prover_reference_functions.cpp:227-238. */
+#define MNT753_FFT 0
+#define MNT753_IFFT 1
+#define MNT753_COSET_FFT 2
+#define MNT753_ICOSET_FFT 3
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+/* replaces B::init_public_params (prover_reference_functions.hpp:25).  device = HIP device ordinal. */
+int mnt753_init(int device);
+const char* mnt753_last_error(void);
+/* number of words (uint64) of one element / point of the given kind */
+size_t mnt753_affine_words(int curve, int group);      /* 24, 48 (MNT4753 G2) or 72 (MNT6753 G2) */
+size_t mnt753_projective_words(int curve, int group);  /* 36, 72 or 108 */
+
+/* ---- device memory helpers (for hosts that do not bring their own allocator) ------------------- */
+int mnt753_dev_alloc(void** dev_ptr, size_t bytes);
+int mnt753_dev_free(void* dev_ptr);
+int mnt753_copy_h2d(void* dev_dst, const void* src, size_t bytes);
+int mnt753_copy_d2h(void* dst, const void* dev_src, size_t bytes);
+int mnt753_sync(void* stream);
+
+/* ---- MSM --------------------------------------------------------------------------------------
+ * A base set is the device-resident, pre-converted image of a vector_G1 / vector_G2 of the parameters
+ * (B::params_A/B1/L/H/B2, prover_reference_functions.hpp:66-70).  The reference loads parameters before
+ * its timing window opens (libsnark/main.cpp:201-203); creating a base set belongs to that phase. */
+typedef struct mnt753_bases mnt753_bases;
+/* affine: n points in the wire format above; on_device != 0 if `affine` is a device pointer */
+int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_device, size_t n, mnt753_bases** out);
+int mnt753_bases_free(mnt753_bases* b);
+size_t mnt753_bases_size(const mnt753_bases* b);
+
+/* replaces B::multiexp_G1 / B::multiexp_G2 (prover_reference_functions.hpp:49-52):
+ *   result = sum_{i < n} scalars[i] * bases[base_offset + i]
+ * scalars: n Fr elements, wire format (Montgomery), device pointer if scalars_on_device != 0.
+ * out_projective: host buffer of mnt753_projective_words() u64 -- X | Y | Z, Montgomery, fully reduced
+ * (NOT normalised to Z = 1; feed it to mnt753_point_to_affine / mnt753_point_add). */
+int mnt753_msm(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n,
+               uint64_t* out_projective, void* stream);
+/* the same, split for multi-GPU use: per-device partial sums are exchanged by the caller (RCCL) and
+ * folded with mnt753_point_add. Identical to mnt753_msm on one device. */
+
+/* window size override (0 = automatic); returns previous value.  Tuning knob, not part of the reference. */
+int mnt753_msm_set_window_bits(int c);
+/* time of the last mnt753_msm call's kernels in milliseconds (HIP events on the launch stream):
+ * index 0 = total, 1 = digits+sort, 2 = bucket accumulation kernel, 3 = bucket reduction, 4 = host tail */
+int mnt753_msm_last_timing(float out_ms[5]);
+
+/* ---- small group operations on the host (O(1) work per proof) ------------------------------------ */
+/* replaces B::G1_add (hpp:32) */
+int mnt753_point_add(int curve, int group, const uint64_t* a_proj, const uint64_t* b_proj, uint64_t* out_proj);
+/* replaces B::G1_scale (hpp:33): scalar is an Fr element in wire (Montgomery) form */
+int mnt753_point_scale(int curve, int group, const uint64_t* scalar, const uint64_t* p_proj, uint64_t* out_proj);
+/* to_affine_coordinates + write_g1/write_g2 encoding (serialization.hpp:44-67): identity -> all zero */
+int mnt753_point_to_affine(int curve, int group, const uint64_t* p_proj, uint64_t* out_affine);
+/* read_g1 / read_g2 decoding (serialization.hpp:84-111): y == 0 -> identity */
+int mnt753_point_from_affine(int curve, int group, const uint64_t* affine, uint64_t* out_proj);
+
+/* ---- FFT over Fr ---------------------------------------------------------------------------------- */
+typedef struct mnt753_domain mnt753_domain;
+/* replaces B::get_evaluation_domain (hpp:30): m must be a power of two <= 2^s (s = 30 MNT4753, 15 MNT6753) */
+int mnt753_domain_create(int curve, size_t m, mnt753_domain** out);
+int mnt753_domain_free(mnt753_domain* d);
+size_t mnt753_domain_size(const mnt753_domain* d);   /* B::domain_get_m (hpp:47) */
+/* replaces B::domain_iFFT / domain_cosetFFT / domain_icosetFFT (hpp:42-45) and libfqfft FFT; in place on
+ * a device vector of m Fr elements in wire format */
+int mnt753_fft(mnt753_domain* d, int kind, uint64_t* dev_vec, void* stream);
+/* replaces B::domain_divide_by_Z_on_coset (hpp:46) */
+int mnt753_divide_by_z_on_coset(mnt753_domain* d, uint64_t* dev_vec, void* stream);
+/* replaces B::vector_Fr_muleq / vector_Fr_subeq (hpp:35-36): a[i] = a[i] (*|-) b[i], i < n */
+int mnt753_vec_muleq(int curve, uint64_t* dev_a, const uint64_t* dev_b, size_t n, void* stream);
+int mnt753_vec_subeq(int curve, uint64_t* dev_a, const uint64_t* dev_b, size_t n, void* stream);
+/* the whole of compute_H (cuda_prover_piecewise.cu:18-53) resident on the device:
+ * dev_ca / dev_cb / dev_cc hold m elements each and are overwritten; dev_h receives m + 1 elements
+ * (coefficients_for_H, last entry 0). */
+int mnt753_compute_h(mnt753_domain* d, uint64_t* dev_ca, uint64_t* dev_cb, uint64_t* dev_cc, uint64_t* dev_h,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNT753_HIP_H */

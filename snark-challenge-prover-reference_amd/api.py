@@ -1,0 +1,242 @@
+"""ctypes binding of include/mnt753_hip.h.  No compute happens in Python; every call lands in
+libmnt753_hip.so, and the loader raises if the library was not built (no fallback path)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+CURVE_MNT4753, CURVE_MNT6753 = 0, 1
+G1, G2 = 1, 2
+FFT, IFFT, COSET_FFT, ICOSET_FFT = 0, 1, 2, 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Mnt753Error(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmnt753_hip.so")
+
+
+def lib():
+    """Load libmnt753_hip.so (built by `make` / __graft_entry__.build()); fail loudly if missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise Mnt753Error(f"{path} not found: build the HIP extension first (make, or __graft_entry__.build())")
+    L = C.CDLL(path)
+    u64p, vp, sz, i = C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t, C.c_int
+    sig = {
+        "mnt753_init": (i, [i]),
+        "mnt753_last_error": (C.c_char_p, []),
+        "mnt753_affine_words": (sz, [i, i]),
+        "mnt753_projective_words": (sz, [i, i]),
+        "mnt753_dev_alloc": (i, [C.POINTER(vp), sz]),
+        "mnt753_dev_free": (i, [vp]),
+        "mnt753_copy_h2d": (i, [vp, vp, sz]),
+        "mnt753_copy_d2h": (i, [vp, vp, sz]),
+        "mnt753_sync": (i, [vp]),
+        "mnt753_bases_create": (i, [i, i, vp, i, sz, C.POINTER(vp)]),
+        "mnt753_bases_free": (i, [vp]),
+        "mnt753_bases_size": (sz, [vp]),
+        "mnt753_msm": (i, [vp, sz, vp, i, sz, u64p, vp]),
+        "mnt753_msm_set_window_bits": (i, [i]),
+        "mnt753_msm_last_timing": (i, [C.POINTER(C.c_float)]),
+        "mnt753_point_add": (i, [i, i, u64p, u64p, u64p]),
+        "mnt753_point_scale": (i, [i, i, u64p, u64p, u64p]),
+        "mnt753_point_to_affine": (i, [i, i, u64p, u64p]),
+        "mnt753_point_from_affine": (i, [i, i, u64p, u64p]),
+        "mnt753_domain_create": (i, [i, sz, C.POINTER(vp)]),
+        "mnt753_domain_free": (i, [vp]),
+        "mnt753_domain_size": (sz, [vp]),
+        "mnt753_fft": (i, [vp, i, vp, vp]),
+        "mnt753_divide_by_z_on_coset": (i, [vp, vp, vp]),
+        "mnt753_vec_muleq": (i, [i, vp, vp, sz, vp]),
+        "mnt753_vec_subeq": (i, [i, vp, vp, sz, vp]),
+        "mnt753_compute_h": (i, [vp, vp, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = the library does not export what the header declares
+        fn.restype, fn.argtypes = res, args
+    _LIB = L
+    return L
+
+
+EXPORTS = None  # filled lazily by tests: the list of symbols include/mnt753_hip.h declares
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise Mnt753Error(f"{what} failed (rc={rc}): {lib().mnt753_last_error().decode()}")
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def init(device=0):
+    _check(lib().mnt753_init(int(device)), "mnt753_init")
+
+
+def affine_words(curve, group):
+    return int(lib().mnt753_affine_words(curve, group))
+
+
+def projective_words(curve, group):
+    return int(lib().mnt753_projective_words(curve, group))
+
+
+class BaseSet:
+    """Device-resident vector_G1 / vector_G2 (B::params_A ... of the reference)."""
+
+    def __init__(self, curve, group, affine, on_device=False, n=None):
+        self.curve, self.group = curve, group
+        self._h = C.c_void_p()
+        if on_device:
+            ptr, cnt = C.c_void_p(int(affine)), int(n)
+        else:
+            self._keep = np.ascontiguousarray(affine, dtype=np.uint64)
+            cnt = self._keep.size // affine_words(curve, group) if n is None else int(n)
+            ptr = C.c_void_p(self._keep.ctypes.data)
+        _check(lib().mnt753_bases_create(curve, group, ptr, 1 if on_device else 0, cnt, C.byref(self._h)), "mnt753_bases_create")
+        self.n = cnt
+
+    def msm(self, scalars, n=None, base_offset=0, on_device=False, stream=None):
+        """sum scalars[i] * bases[base_offset + i]; returns the projective wire words (numpy u64)."""
+        out = np.zeros(projective_words(self.curve, self.group), dtype=np.uint64)
+        if on_device:
+            sptr, cnt = C.c_void_p(int(scalars)), int(n)
+        else:
+            keep = np.ascontiguousarray(scalars, dtype=np.uint64)
+            cnt = keep.size // 12 if n is None else int(n)
+            sptr = C.c_void_p(keep.ctypes.data)
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+        _check(lib().mnt753_msm(self._h, base_offset, sptr, 1 if on_device else 0, cnt,
+                                out.ctypes.data_as(C.POINTER(C.c_uint64)), st), "mnt753_msm")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mnt753_bases_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def msm_last_timing():
+    t = (C.c_float * 5)()
+    _check(lib().mnt753_msm_last_timing(t), "mnt753_msm_last_timing")
+    return dict(total_ms=t[0], sort_ms=t[1], accumulate_ms=t[2], reduce_ms=t[3], host_ms=t[4])
+
+
+def point_add(curve, group, a, b):
+    a, pa = _u64(a); b, pb = _u64(b)
+    out = np.zeros(projective_words(curve, group), dtype=np.uint64)
+    _check(lib().mnt753_point_add(curve, group, pa, pb, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_point_add")
+    return out
+
+
+def point_scale(curve, group, scalar, p):
+    s, ps = _u64(scalar); p, pp = _u64(p)
+    out = np.zeros(projective_words(curve, group), dtype=np.uint64)
+    _check(lib().mnt753_point_scale(curve, group, ps, pp, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_point_scale")
+    return out
+
+
+def point_to_affine(curve, group, p):
+    p, pp = _u64(p)
+    out = np.zeros(affine_words(curve, group), dtype=np.uint64)
+    _check(lib().mnt753_point_to_affine(curve, group, pp, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_point_to_affine")
+    return out
+
+
+def point_from_affine(curve, group, a):
+    a, pa = _u64(a)
+    out = np.zeros(projective_words(curve, group), dtype=np.uint64)
+    _check(lib().mnt753_point_from_affine(curve, group, pa, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_point_from_affine")
+    return out
+
+
+class DeviceBuffer:
+    """Device memory owned through the C ABI (for callers without torch)."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        _check(lib().mnt753_dev_alloc(C.byref(self.ptr), self.nbytes), "mnt753_dev_alloc")
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        _check(lib().mnt753_copy_h2d(b.ptr, C.c_void_p(a.ctypes.data), a.nbytes), "mnt753_copy_h2d")
+        return b
+
+    def to_numpy(self, dtype=np.uint64):
+        out = np.zeros(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _check(lib().mnt753_copy_d2h(C.c_void_p(out.ctypes.data), self.ptr, self.nbytes), "mnt753_copy_d2h")
+        return out
+
+    def close(self):
+        if self.ptr and self.ptr.value:
+            lib().mnt753_dev_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Domain:
+    """basic_radix2_domain over Fr of the curve (B::get_evaluation_domain)."""
+
+    def __init__(self, curve, m):
+        self.curve, self.m = curve, int(m)
+        self._h = C.c_void_p()
+        _check(lib().mnt753_domain_create(curve, self.m, C.byref(self._h)), "mnt753_domain_create")
+
+    def fft(self, kind, dev_ptr, stream=None):
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+        _check(lib().mnt753_fft(self._h, kind, C.c_void_p(int(dev_ptr)), st), "mnt753_fft")
+
+    def divide_by_z_on_coset(self, dev_ptr, stream=None):
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+        _check(lib().mnt753_divide_by_z_on_coset(self._h, C.c_void_p(int(dev_ptr)), st), "mnt753_divide_by_z_on_coset")
+
+    def compute_h(self, ca, cb, cc, h, stream=None):
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+        _check(lib().mnt753_compute_h(self._h, C.c_void_p(int(ca)), C.c_void_p(int(cb)), C.c_void_p(int(cc)),
+                                      C.c_void_p(int(h)), st), "mnt753_compute_h")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mnt753_domain_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def vec_muleq(curve, a_ptr, b_ptr, n, stream=None):
+    st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+    _check(lib().mnt753_vec_muleq(curve, C.c_void_p(int(a_ptr)), C.c_void_p(int(b_ptr)), n, st), "mnt753_vec_muleq")
+
+
+def vec_subeq(curve, a_ptr, b_ptr, n, stream=None):
+    st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+    _check(lib().mnt753_vec_subeq(curve, C.c_void_p(int(a_ptr)), C.c_void_p(int(b_ptr)), n, st), "mnt753_vec_subeq")

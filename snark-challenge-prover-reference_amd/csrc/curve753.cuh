@@ -1,0 +1,301 @@
+// MNT4753 / MNT6753 group law on the device: G1 over Fq, G2 over Fq2 (MNT4) / Fq3 (MNT6).
+//
+// Reference formulas (homogeneous projective, identity (0:1:0)):
+//   depends/libff/libff/algebra/curves/mnt753/mnt4753/mnt4753_g1.cpp:134-207 (operator+),
+//   :265-313 (mixed_add), :315-346 (dbl); mnt4753_g2.cpp:31-34 (mul_by_a), mnt6753_g2.cpp:38-41;
+//   extension fields depends/libff/libff/algebra/fields/fp2.tcc:79-90, fp3.tcc:83-96.
+//
+// Structure: a point operation is a *micro-program* (one field multiplication per step)
+// executed by pt_vm().  Each lane carries its own program counter, so a wave can mix lanes that
+// add, lanes that must double (P == Q) and idle lanes, while the kernel contains exactly ONE
+// inlined instance of the 1458-MAD multiplier (~14 KB of code): the hot loop stays inside the
+// 64 KB instruction cache instead of streaming ~160 KB of straight-line code per addition.
+#pragma once
+#include "fp753.cuh"
+
+namespace mnt753 {
+
+// ------------------------------------------------------------------------------------------
+// Coordinate fields.  Every field class provides: E, DEG, mul, add, sub, neg, is_zero, zero, one.
+// ------------------------------------------------------------------------------------------
+template <int M>
+struct FieldFp {
+  using E = Fp<M>;
+  static constexpr int DEG = 1;
+  static constexpr int MOD = M;
+  static HD void mul(E& r, const E& a, const E& b) { fp_mul(r, a, b); }
+  static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
+  static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
+  static HD void neg(E& r, const E& a) { fp_neg(r, a); }
+  static HD bool is_zero(const E& a) { return fp_is_zero(a); }
+  static HD void zero(E& r) { fp_zero(r); }
+  static HD void one(E& r) { fp_one(r); }
+  static HD Fp<M>& comp(E& a, int) { return a; }
+  static HD const Fp<M>& comp(const E& a, int) { return a; }
+};
+
+template <int M>
+struct Fp2E {
+  Fp<M> c0, c1;
+};
+template <int M>
+struct Fp3E {
+  Fp<M> c0, c1, c2;
+};
+
+// Fq2 = Fq[u]/(u^2 - NR): Karatsuba, 3 base multiplications through ONE multiplier instance.
+template <int M, unsigned NR>
+struct FieldFp2 {
+  using E = Fp2E<M>;
+  static constexpr int DEG = 2;
+  static constexpr int MOD = M;
+  static HD void mul(E& r, const E& x, const E& y) {
+    Fp<M> a, b, t, aA, bB, sx, sy;
+    fp_add(sx, x.c0, x.c1);
+    fp_add(sy, y.c0, y.c1);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int k = 0; k < 3; ++k) {
+      switch (k) {
+        case 0: a = x.c0; b = y.c0; break;
+        case 1: a = x.c1; b = y.c1; break;
+        default: a = sx; b = sy; break;
+      }
+      fp_mul(t, a, b);
+      switch (k) {
+        case 0: aA = t; break;
+        case 1: bB = t; break;
+        default: break;
+      }
+    }
+    // c0 = aA + NR*bB ; c1 = (a+b)(A+B) - aA - bB
+    Fp<M> nb;
+    fp_mul_small(nb, bB, NR);
+    fp_sub(t, t, aA);
+    fp_sub(r.c1, t, bB);
+    fp_add(r.c0, aA, nb);
+  }
+  static HD void add(E& r, const E& a, const E& b) { fp_add(r.c0, a.c0, b.c0); fp_add(r.c1, a.c1, b.c1); }
+  static HD void sub(E& r, const E& a, const E& b) { fp_sub(r.c0, a.c0, b.c0); fp_sub(r.c1, a.c1, b.c1); }
+  static HD void neg(E& r, const E& a) { fp_neg(r.c0, a.c0); fp_neg(r.c1, a.c1); }
+  static HD bool is_zero(const E& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+  static HD void zero(E& r) { fp_zero(r.c0); fp_zero(r.c1); }
+  static HD void one(E& r) { fp_one(r.c0); fp_zero(r.c1); }
+  static HD Fp<M>& comp(E& a, int i) { return i == 0 ? a.c0 : a.c1; }
+  static HD const Fp<M>& comp(const E& a, int i) { return i == 0 ? a.c0 : a.c1; }
+};
+
+// Fq3 = Fq[u]/(u^3 - NR): Karatsuba, 6 base multiplications through ONE multiplier instance.
+template <int M, unsigned NR>
+struct FieldFp3 {
+  using E = Fp3E<M>;
+  static constexpr int DEG = 3;
+  static constexpr int MOD = M;
+  static HD void mul(E& r, const E& x, const E& y) {
+    Fp<M> a, b, t, aA, bB, cC, t_bc, t_ab, t_ac;
+    Fp<M> x_bc, x_ab, x_ac, y_bc, y_ab, y_ac;
+    fp_add(x_bc, x.c1, x.c2); fp_add(y_bc, y.c1, y.c2);
+    fp_add(x_ab, x.c0, x.c1); fp_add(y_ab, y.c0, y.c1);
+    fp_add(x_ac, x.c0, x.c2); fp_add(y_ac, y.c0, y.c2);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int k = 0; k < 6; ++k) {
+      switch (k) {
+        case 0: a = x.c0; b = y.c0; break;
+        case 1: a = x.c1; b = y.c1; break;
+        case 2: a = x.c2; b = y.c2; break;
+        case 3: a = x_bc; b = y_bc; break;
+        case 4: a = x_ab; b = y_ab; break;
+        default: a = x_ac; b = y_ac; break;
+      }
+      fp_mul(t, a, b);
+      switch (k) {
+        case 0: aA = t; break;
+        case 1: bB = t; break;
+        case 2: cC = t; break;
+        case 3: t_bc = t; break;
+        case 4: t_ab = t; break;
+        default: t_ac = t; break;
+      }
+    }
+    // c0 = aA + NR*((b+c)(B+C) - bB - cC)
+    // c1 = (a+b)(A+B) - aA - bB + NR*cC
+    // c2 = (a+c)(A+C) - aA + bB - cC
+    Fp<M> u, v;
+    fp_sub(u, t_bc, bB); fp_sub(u, u, cC); fp_mul_small(v, u, NR); fp_add(r.c0, aA, v);
+    fp_sub(u, t_ab, aA); fp_sub(u, u, bB); fp_mul_small(v, cC, NR); fp_add(r.c1, u, v);
+    fp_sub(u, t_ac, aA); fp_add(u, u, bB); fp_sub(r.c2, u, cC);
+  }
+  static HD void add(E& r, const E& a, const E& b) { fp_add(r.c0, a.c0, b.c0); fp_add(r.c1, a.c1, b.c1); fp_add(r.c2, a.c2, b.c2); }
+  static HD void sub(E& r, const E& a, const E& b) { fp_sub(r.c0, a.c0, b.c0); fp_sub(r.c1, a.c1, b.c1); fp_sub(r.c2, a.c2, b.c2); }
+  static HD void neg(E& r, const E& a) { fp_neg(r.c0, a.c0); fp_neg(r.c1, a.c1); fp_neg(r.c2, a.c2); }
+  static HD bool is_zero(const E& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1) && fp_is_zero(a.c2); }
+  static HD void zero(E& r) { fp_zero(r.c0); fp_zero(r.c1); fp_zero(r.c2); }
+  static HD void one(E& r) { fp_one(r.c0); fp_zero(r.c1); fp_zero(r.c2); }
+  static HD Fp<M>& comp(E& a, int i) { return i == 0 ? a.c0 : (i == 1 ? a.c1 : a.c2); }
+  static HD const Fp<M>& comp(const E& a, int i) { return i == 0 ? a.c0 : (i == 1 ? a.c1 : a.c2); }
+};
+
+// ------------------------------------------------------------------------------------------
+// Curve configurations: coordinate field F, scalar-field modulus FR, and mul_by_a.
+// ------------------------------------------------------------------------------------------
+struct Mnt4G1 {  // y^2 = x^3 + 2x + b over Fq = B          (mnt4753_init.cpp:119)
+  using F = FieldFp<MOD_B>;
+  static constexpr int FR = MOD_A;
+  static HD void mul_by_a(F::E& r, const F::E& x) { fp_add(r, x, x); }
+};
+struct Mnt6G1 {  // y^2 = x^3 + 11x + b over Fq = A         (mnt6753_init.cpp:130)
+  using F = FieldFp<MOD_A>;
+  static constexpr int FR = MOD_B;
+  static HD void mul_by_a(F::E& r, const F::E& x) { fp_mul_small(r, x, 11u); }
+};
+struct Mnt4G2 {  // twist over Fq2, a' = (2*13, 0): mul_by_a(c0,c1) = (26 c0, 26 c1)   (mnt4753_g2.cpp:31-34)
+  using F = FieldFp2<MOD_B, 13u>;
+  static constexpr int FR = MOD_A;
+  static HD void mul_by_a(F::E& r, const F::E& x) { fp_mul_small(r.c0, x.c0, 26u); fp_mul_small(r.c1, x.c1, 26u); }
+};
+struct Mnt6G2 {  // twist over Fq3, a' = (0,0,11): mul_by_a(c0,c1,c2) = (121 c1, 121 c2, 11 c0)  (mnt6753_g2.cpp:38-41)
+  using F = FieldFp3<MOD_A, 11u>;
+  static constexpr int FR = MOD_B;
+  static HD void mul_by_a(F::E& r, const F::E& x) {
+    F::E t;
+    fp_mul_small(t.c0, x.c1, 121u);
+    fp_mul_small(t.c1, x.c2, 121u);
+    fp_mul_small(t.c2, x.c0, 11u);
+    r = t;
+  }
+};
+
+template <class C>
+struct Proj {
+  typename C::F::E X, Y, Z;
+};
+template <class C>
+struct Aff {
+  typename C::F::E x, y;
+};
+
+template <class C>
+HD bool pt_is_zero(const Proj<C>& P) { return C::F::is_zero(P.Z); }
+
+template <class C>
+HD void pt_set_zero(Proj<C>& P) { C::F::zero(P.X); C::F::one(P.Y); C::F::zero(P.Z); }
+
+// ------------------------------------------------------------------------------------------
+// The point-operation VM.  Program counters:
+//    0..10  mixed/projective addition tail (P += Q, Q with Z2 == 1 for pc 0,1)
+//   16..26  doubling  P = 2P
+//   32..36  projective addition prologue (then falls into pc 2)
+//   PC_END  idle
+// ------------------------------------------------------------------------------------------
+constexpr int PC_MADD = 0;
+constexpr int PC_DBL = 16;
+constexpr int PC_ADD = 32;
+constexpr int PC_END = 63;
+
+// P, Q: P is updated in place.  Preconditions: for PC_MADD / PC_ADD both P and Q are non-zero
+// (the callers handle the identity); PC_DBL needs P non-zero.  Q.Z is only read by PC_ADD.
+template <class C, bool WITH_ADD>
+HD void pt_vm(Proj<C>& P, const Proj<C>& Q, int pc) {
+  using F = typename C::F;
+  using E = typename F::E;
+  E u, v, t3, t4, t5, a, b, r;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+  while (pc != PC_END) {
+    switch (pc) {
+      case 0: a = P.Z; b = Q.X; break;
+      case 1: a = P.Z; b = Q.Y; break;
+      case 2: a = u; b = u; break;
+      case 3: a = v; b = v; break;
+      case 4: a = v; b = t4; break;
+      case 5: a = t4; b = P.X; break;
+      case 6: a = t3; b = P.Z; break;
+      case 7: a = v; b = t3; break;
+      case 8: a = u; b = t4; break;
+      case 9: a = t5; b = P.Y; break;
+      case 10: a = t5; b = P.Z; break;
+      case 16: a = P.X; b = P.X; break;
+      case 17: a = P.Z; b = P.Z; break;
+      case 18: a = P.Y; b = P.Z; break;
+      case 19: a = v; b = v; break;
+      case 20: a = v; b = t4; break;
+      case 21: a = P.Y; b = v; break;
+      case 22: a = t4; b = t4; break;
+      case 23: F::add(a, P.X, t4); b = a; break;
+      case 24: a = u; b = u; break;
+      case 25: a = t3; b = v; break;
+      case 26: F::sub(a, t4, t3); b = u; break;
+      default:
+        if (WITH_ADD) {
+          switch (pc) {
+            case 32: a = P.X; b = Q.Z; break;
+            case 33: a = P.Y; b = Q.Z; break;
+            case 34: a = Q.X; b = P.Z; break;
+            case 35: a = Q.Y; b = P.Z; break;
+            default: a = P.Z; b = Q.Z; break;  // 36
+          }
+        }
+        break;
+    }
+    F::mul(r, a, b);
+    switch (pc) {
+      case 0: F::sub(v, r, P.X); pc = 1; break;
+      case 1:
+        F::sub(u, r, P.Y);
+        pc = (F::is_zero(u) && F::is_zero(v)) ? PC_DBL : 2;
+        break;
+      case 2: t3 = r; pc = 3; break;
+      case 3: t4 = r; pc = 4; break;
+      case 4: t5 = r; pc = 5; break;
+      case 5: t4 = r; pc = 6; break;
+      case 6:
+        F::sub(r, r, t5); F::sub(r, r, t4); F::sub(t3, r, t4);  // A = uu*Z - vvv - 2R
+        F::sub(t4, t4, t3);                                      // R - A
+        pc = 7;
+        break;
+      case 7: P.X = r; pc = 8; break;
+      case 8: t4 = r; pc = 9; break;
+      case 9: F::sub(P.Y, t4, r); pc = 10; break;
+      case 10: P.Z = r; pc = PC_END; break;
+      case 16: t3 = r; pc = 17; break;                           // XX
+      case 17: {                                                 // w = a*ZZ + 3*XX
+        E az;
+        C::mul_by_a(az, r);
+        F::add(u, t3, t3); F::add(u, u, t3); F::add(u, u, az);
+        pc = 18;
+      } break;
+      case 18: F::add(v, r, r); pc = 19; break;                  // s = 2*Y1*Z1
+      case 19: t4 = r; pc = 20; break;                           // ss
+      case 20: P.Z = r; pc = 21; break;                          // Z3 = sss
+      case 21: t4 = r; pc = 22; break;                           // R = Y1*s
+      case 22: t5 = r; pc = 23; break;                           // RR
+      case 23: F::sub(r, r, t3); F::sub(t4, r, t5); pc = 24; break;   // B = (X1+R)^2 - XX - RR
+      case 24: F::sub(r, r, t4); F::sub(t3, r, t4); pc = 25; break;   // h = w^2 - 2B
+      case 25: P.X = r; pc = 26; break;                          // X3 = h*s
+      case 26: F::sub(r, r, t5); F::sub(P.Y, r, t5); pc = PC_END; break;  // Y3 = w*(B-h) - 2RR
+      default:
+        if (WITH_ADD) {
+          switch (pc) {
+            case 32: P.X = r; pc = 33; break;                    // X1Z2
+            case 33: P.Y = r; pc = 34; break;                    // Y1Z2
+            case 34: F::sub(v, r, P.X); pc = 35; break;          // v = X2Z1 - X1Z2
+            case 35:
+              F::sub(u, r, P.Y);                                 // u = Y2Z1 - Y1Z2
+              if (F::is_zero(u) && F::is_zero(v)) { P.X = Q.X; P.Y = Q.Y; P.Z = Q.Z; pc = PC_DBL; }
+              else pc = 36;
+              break;
+            default: P.Z = r; pc = 2; break;                     // Z1Z2, continue with shared tail
+          }
+        } else {
+          pc = PC_END;
+        }
+        break;
+    }
+  }
+}
+
+}  // namespace mnt753

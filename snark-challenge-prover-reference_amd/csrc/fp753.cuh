@@ -1,0 +1,242 @@
+// 753-bit prime-field arithmetic for gfx950 (MI355X) -- device representation.
+//
+// Replaces, on the device, libff's Fp_model<12, modulus> (reference:
+// depends/libff/libff/algebra/fields/fp.tcc:161-186 mul_reduce, :405-417 +=, :491-508 -=).
+//
+// Design (measured, profiles/r01/valu_rates_mi355x.txt + mulbench_mi355x.txt):
+//   * v_mad_u64_u32 (32x32+64 -> 64) issues in ~5 cycles per SIMD, only ~1.25x a v_mul_lo_u32
+//     and ~1.7x a plain v_add_u32, while a carry-propagating v_add_co/v_addc_co pair costs
+//     ~1.5x a MAD.  Carries, not multiplies, are the expensive thing on this chip.
+//   * so an element is 27 limbs x 28 bits (756 bits) instead of 24 x 32: a 28x28-bit product is
+//     < 2^56 and 54 of them fit a 64-bit column accumulator, which makes the whole Montgomery
+//     product (finely integrated product scanning) a pure chain of 1458 v_mad_u64_u32 with one
+//     shift+mask per column and NO carry instructions.
+//   * Montgomery radix R' = 2^756; values are kept lazily in [0, 2p) (2p < 2^754):
+//     inputs < 2p give outputs < p(4p/R' + 1) < 1.45p, so a multiply needs no final subtraction.
+//   * the wire format (12 x u64, Montgomery R = 2^768, canonical) is converted at kernel
+//     boundaries with one multiply by a constant (k_in / k_out below).
+//
+// Everything is __host__ __device__ so the same source can be exercised by a CPU harness during
+// development; the product only ever runs it on the GPU.
+#pragma once
+#include <stdint.h>
+#include "mnt753_constants.h"
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define HD __host__ __device__ __forceinline__
+#else
+#define HD inline
+#endif
+
+namespace mnt753 {
+
+template <int M>
+struct Fp {
+  uint32_t l[NL];
+};
+
+// ---- Montgomery product, radix 2^756, two interleaved column accumulators ------------------
+// r = a*b*2^-756 mod p, r < 2p provided a*b < 4p^2 (e.g. a,b < 2p; or a < 4p, b < p).
+// Limbs of a may be up to 2^29 (one un-normalised addition) -- the column bound still holds.
+template <int M>
+HD void fp_mul(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
+  uint64_t acc = 0, acc2 = 0;
+  uint32_t m[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += acc2;
+    acc2 = 0;
+    m[k] = ((uint32_t)acc * FPC[M].inv) & LMASK;
+    acc += (uint64_t)m[k] * FPC[M].p[0];
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += acc2;
+    acc2 = 0;
+    r.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+}
+
+// s (normalised limbs, value < 4p) -> r = s mod 2p, in [0, 2p)
+template <int M>
+HD void fp_reduce2p(Fp<M>& r, const uint32_t s[NL]) {
+  uint32_t d[NL];
+  int32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int32_t t = (int32_t)s[i] - (int32_t)FPC[M].p2[i] + bw;
+    d[i] = (uint32_t)t & LMASK;
+    bw = t >> LB;
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = bw < 0 ? s[i] : d[i];
+}
+
+template <int M>
+HD void fp_add(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
+  uint32_t s[NL], c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    uint32_t t = a.l[i] + b.l[i] + c;
+    s[i] = t & LMASK;
+    c = t >> LB;
+  }
+  fp_reduce2p<M>(r, s);
+}
+
+// r = a - b (mod p), computed as a - b + 2p then reduced into [0, 2p)
+template <int M>
+HD void fp_sub(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
+  uint32_t s[NL];
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int32_t t = (int32_t)a.l[i] - (int32_t)b.l[i] + (int32_t)FPC[M].p2[i] + c;
+    s[i] = (uint32_t)t & LMASK;
+    c = t >> LB;
+  }
+  fp_reduce2p<M>(r, s);
+}
+
+template <int M>
+HD void fp_zero(Fp<M>& r) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = 0;
+}
+
+template <int M>
+HD void fp_one(Fp<M>& r) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = FPC[M].one[i];
+}
+
+template <int M>
+HD void fp_neg(Fp<M>& r, const Fp<M>& a) {
+  Fp<M> z;
+  fp_zero(z);
+  fp_sub(r, z, a);
+}
+
+// a in [0, 2p): a == 0 (mod p)  <=>  a is 0 or p
+template <int M>
+HD bool fp_is_zero(const Fp<M>& a) {
+  uint32_t o0 = 0, o1 = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    o0 |= a.l[i];
+    o1 |= a.l[i] ^ FPC[M].p[i];
+  }
+  return o0 == 0 || o1 == 0;
+}
+
+// [0,2p) -> canonical [0,p)
+template <int M>
+HD void fp_canon(Fp<M>& r, const Fp<M>& a) {
+  uint32_t d[NL];
+  int32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int32_t t = (int32_t)a.l[i] - (int32_t)FPC[M].p[i] + bw;
+    d[i] = (uint32_t)t & LMASK;
+    bw = t >> LB;
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = bw < 0 ? a.l[i] : d[i];
+}
+
+// r = k*a for a small non-negative integer k (curve / twist coefficients 2, 11, 13, 26, 121):
+// binary double-and-add on the lazy representation; ~2*log2(k) additions, no multiplier instance.
+template <int M>
+HD void fp_mul_small(Fp<M>& r, const Fp<M>& a, unsigned k) {
+  Fp<M> acc, base = a;
+  fp_zero(acc);
+  bool have = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+  for (; k != 0; k >>= 1) {
+    if (k & 1) {
+      if (have) fp_add(acc, acc, base);
+      else { acc = base; have = true; }
+    }
+    if (k > 1) fp_add(base, base, base);
+  }
+  r = acc;
+}
+
+// ---- wire-format conversion -------------------------------------------------------------
+// 24 little-endian u32 words (768 bits) -> 27 raw 28-bit limbs (no Montgomery change)
+template <int M>
+HD void fp_unpack(Fp<M>& r, const uint32_t w[24]) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int bit = LB * i, wi = bit >> 5, sh = bit & 31;
+    uint32_t lo = w[wi];
+    uint32_t hi = (wi + 1 < 24) ? w[wi + 1] : 0u;
+    uint32_t v = sh == 0 ? lo : (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+    r.l[i] = v & LMASK;
+  }
+}
+
+// 27 normalised limbs (value < 2^756; caller guarantees < 2^768 trivially) -> 24 u32 words
+template <int M>
+HD void fp_pack(uint32_t w[24], const Fp<M>& a) {
+#pragma unroll
+  for (int j = 0; j < 24; ++j) {
+    // word j covers bits [32j, 32j+32): limbs floor(32j/28) and the next one or two
+    const int bit = 32 * j, li = bit / LB, sh = bit - li * LB;  // sh in [0,28)
+    uint64_t v = (uint64_t)a.l[li] >> sh;
+    if (li + 1 < NL) v |= (uint64_t)a.l[li + 1] << (LB - sh);
+    if (li + 2 < NL) v |= (uint64_t)a.l[li + 2] << (2 * LB - sh);
+    w[j] = (uint32_t)v;
+  }
+}
+
+template <int M>
+HD void fp_const_limbs(Fp<M>& r, const uint32_t (&c)[NL]) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c[i];
+}
+
+// wire (Montgomery R=2^768, canonical) -> internal (Montgomery R'=2^756, [0,2p))
+template <int M>
+HD void fp_from_wire(Fp<M>& r, const uint32_t w[24]) {
+  Fp<M> raw, k;
+  fp_unpack(raw, w);
+  fp_const_limbs(k, FPC[M].k_in);
+  fp_mul(r, raw, k);
+}
+
+// internal -> wire (canonical)
+template <int M>
+HD void fp_to_wire(uint32_t w[24], const Fp<M>& a) {
+  Fp<M> k, t, c;
+  fp_const_limbs(k, FPC[M].k_out);
+  fp_mul(t, a, k);
+  fp_canon(c, t);
+  fp_pack(w, c);
+}
+
+// wire Montgomery -> plain integer (libff as_bigint, fp.tcc:227-238), packed 24 x u32
+template <int M>
+HD void fp_wire_to_integer(uint32_t w_out[24], const uint32_t w_in[24]) {
+  Fp<M> raw, k, t, c;
+  fp_unpack(raw, w_in);
+  fp_const_limbs(k, FPC[M].k_std);
+  fp_mul(t, raw, k);
+  fp_canon(c, t);
+  fp_pack(w_out, c);
+}
+
+}  // namespace mnt753

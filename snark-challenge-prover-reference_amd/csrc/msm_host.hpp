@@ -1,0 +1,214 @@
+// Host orchestration of the MSM kernels (templates; instantiated once per curve/group in msm_inst_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mnt753_hip.h"
+#include "common_host.hpp"
+#include "host_field.hpp"
+#include "msm_kernels.cuh"
+#include "msm_types.hpp"
+
+using namespace mnt753;
+
+namespace mnt753 {
+extern int g_window_bits_override;
+extern float g_last_timing[5];
+}
+namespace {
+
+
+// window size: minimise  N*W (bucket adds)  +  ~3 * nb * W (reduction adds, incl. the k0*run tail)
+int pick_window_bits(size_t n) {
+  if (g_window_bits_override > 0) return g_window_bits_override;
+  if (const char* e = getenv("MNT753_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 22) return v; }
+  int best = 2; double best_cost = 1e300;
+  for (int c = 2; c <= 20; ++c) {
+    double W = (754 + c - 1) / c;
+    double cost = W * ((double)n + 3.0 * (double)(1u << (c - 1)) * 14.0 / 11.0);
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+MsmPlan make_plan(size_t n) {
+  MsmPlan p;
+  p.c = pick_window_bits(n);
+  p.W = (754 + p.c - 1) / p.c;
+  p.nb = 1u << (p.c - 1);
+  p.n_buckets = (uint32_t)p.W * p.nb;
+  // lanes: aim at `rounds` full rounds of the machine (256 CUs x 256 lanes, one wave per SIMD)
+  const uint64_t entries = (uint64_t)p.W * n;
+  int rounds = 2;
+  if (const char* e = getenv("MNT753_MSM_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 64) rounds = v; }
+  uint64_t lanes_target = (uint64_t)65536 * rounds;
+  uint64_t T = (entries + lanes_target - 1) / lanes_target;
+  if (T < 16) T = 16;
+  p.T = (uint32_t)T;
+  p.n_lanes = (uint32_t)((entries + T - 1) / T);
+  if (p.n_lanes == 0) p.n_lanes = 1;
+  // reduce chunk: ~one round of lanes
+  uint32_t L = 1;
+  while ((uint64_t)p.n_buckets / L > 65536 && L < p.nb) L <<= 1;
+  if (const char* e = getenv("MNT753_MSM_L")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v <= p.nb && (v & (v - 1)) == 0) L = v; }
+  p.L = L;
+  p.n_chunks = p.n_buckets / L;
+  return p;
+}
+
+}  // namespace
+
+
+namespace {
+
+template <class C>
+int proj_w() { return proj_words<C>(); }
+
+void free_ws(mnt753_bases* b) {
+  void* ptrs[] = {b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
+                  b->d_edges, b->d_edge_bucket, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
+  b->d_digits = nullptr; b->d_hist = b->d_offsets = b->d_cursor = b->d_blocksums = b->d_total = nullptr;
+  b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
+  b->h_wire_out = nullptr; b->d_scalars_stage = nullptr;
+  b->ws_n = 0;
+}
+
+template <class C>
+int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
+  if (b->ws_n >= n && b->ws_plan.c == p.c && b->ws_plan.T == p.T && b->ws_plan.L == p.L && b->ws_plan.n_lanes >= p.n_lanes) return 0;
+  free_ws(b);
+  const size_t PW = proj_words<C>();
+  const size_t nscan_blocks = ((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  HIP_TRY(hipMalloc(&b->d_digits, sizeof(int32_t) * (size_t)p.W * n));
+  HIP_TRY(hipMalloc(&b->d_hist, sizeof(uint32_t) * (size_t)p.n_buckets));
+  HIP_TRY(hipMalloc(&b->d_offsets, sizeof(uint32_t) * ((size_t)p.n_buckets + 1)));
+  HIP_TRY(hipMalloc(&b->d_cursor, sizeof(uint32_t) * (size_t)p.n_buckets));
+  HIP_TRY(hipMalloc(&b->d_blocksums, sizeof(uint32_t) * (nscan_blocks + 1)));
+  HIP_TRY(hipMalloc(&b->d_total, sizeof(uint32_t) * 4));
+  HIP_TRY(hipMalloc(&b->d_sorted, sizeof(uint32_t) * (size_t)p.W * n));
+  HIP_TRY(hipMalloc(&b->d_buckets, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
+  HIP_TRY(hipMalloc(&b->d_edges, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
+  HIP_TRY(hipMalloc(&b->d_edge_bucket, sizeof(uint32_t) * 2 * (size_t)p.n_lanes));
+  HIP_TRY(hipMalloc(&b->d_part_a, sizeof(uint32_t) * PW * (size_t)p.n_chunks));
+  HIP_TRY(hipMalloc(&b->d_part_b, sizeof(uint32_t) * PW * ((size_t)p.n_chunks / 2 + (size_t)p.W)));
+  HIP_TRY(hipMalloc(&b->d_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_chunks));
+  HIP_TRY(hipMalloc(&b->d_wire_out, sizeof(uint32_t) * 3 * wire_coord_words<C>() * (size_t)p.W));
+  HIP_TRY(hipHostMalloc(&b->h_wire_out, sizeof(uint32_t) * 3 * wire_coord_words<C>() * (size_t)p.W));
+  HIP_TRY(hipMalloc(&b->d_scalars_stage, 96 * n));
+  b->ws_n = n;
+  b->ws_plan = p;
+  return 0;
+}
+
+template <class C>
+int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_t n) {
+  const size_t wire_bytes = n * 2 * wire_coord_words<C>() * 4;
+  HIP_TRY(hipMalloc(&b->d_aff, sizeof(uint32_t) * aff_words<C>() * std::max<size_t>(n, 1)));
+  HIP_TRY(hipMalloc(&b->d_inf, std::max<size_t>(n, 1)));
+  if (n == 0) return 0;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(affine);
+  uint32_t* staged = nullptr;
+  if (!on_device) {
+    HIP_TRY(hipMalloc(&staged, wire_bytes));
+    HIP_TRY(hipMemcpy(staged, affine, wire_bytes, hipMemcpyHostToDevice));
+    src = staged;
+  }
+  hipLaunchKernelGGL((k_bases_to_internal<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, b->d_aff, b->d_inf, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  if (staged) HIP_TRY(hipFree(staged));
+  return 0;
+}
+
+template <class HC>
+void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
+  using P = host::HPoint<HC>;
+  const int PWW = 36 * HC::F::DEG;
+  P acc = P::zero();
+  for (int w = W - 1; w >= 0; --w) {
+    if (!acc.is_zero())
+      for (int k = 0; k < c; ++k) acc = acc.dbl();
+    acc = acc.add(P::from_wire(wire_pts + (size_t)w * PWW));
+  }
+  acc.to_wire(out);
+}
+
+template <class C, class HC>
+int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n, uint64_t* out,
+          hipStream_t st) {
+  const int PWW = 36 * HC::F::DEG;  // projective words (u64) on the wire
+  if (n == 0) {
+    host::HPoint<HC>::zero().to_wire(out);
+    return 0;
+  }
+  MsmPlan p = make_plan(n);
+  if (int rc = ensure_ws<C>(b, n, p)) return rc;
+  for (int i = 0; i < 5; ++i)
+    if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
+  const uint32_t* d_scal;
+  if (scalars_on_device) {
+    d_scal = reinterpret_cast<const uint32_t*>(scalars);
+  } else {
+    HIP_TRY(hipMemcpyAsync(b->d_scalars_stage, scalars, 96 * n, hipMemcpyHostToDevice, st));
+    d_scal = reinterpret_cast<const uint32_t*>(b->d_scalars_stage);
+  }
+  const uint32_t* d_aff = b->d_aff + base_offset * aff_words<C>();
+  const uint8_t* d_inf = b->d_inf + base_offset;
+  const size_t PW = proj_words<C>();
+
+  HIP_TRY(hipEventRecord(b->ev[0], st));
+  HIP_TRY(hipMemsetAsync(b->d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
+  const unsigned gb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_hist, n, p.c, p.W);
+  const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_hist, b->d_offsets, b->d_blocksums, (size_t)p.n_buckets);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
+  hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total,
+                     (size_t)p.n_buckets);
+  hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_cursor, b->d_sorted, n, p.c, p.W);
+  HIP_TRY(hipEventRecord(b->ev[1], st));
+  hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
+                     p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
+  HIP_TRY(hipEventRecord(b->ev[2], st));
+  hipLaunchKernelGGL((k_edge_combine<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_edges, b->d_edge_bucket,
+                     b->d_buckets, 2 * p.n_lanes);
+  hipLaunchKernelGGL((k_bucket_reduce<C>), dim3((p.n_chunks + 255) / 256), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,
+                     b->d_tmp, p.nb, p.L, p.n_chunks, p.c - 1);
+  // tree: [W][n_in] -> [W][1]
+  uint32_t n_in = p.nb / p.L;
+  uint32_t* cur = b->d_part_a;
+  uint32_t* nxt = b->d_part_b;
+  const uint32_t R = 4;
+  while (n_in > 1) {
+    uint32_t n_out = (n_in + R - 1) / R;
+    hipLaunchKernelGGL((k_tree_sum<C>), dim3(((uint32_t)p.W * n_out + 255) / 256), dim3(256), 0, st, cur, nxt, (uint32_t)p.W, n_in, n_out, R);
+    std::swap(cur, nxt);
+    n_in = n_out;
+  }
+  hipLaunchKernelGGL((k_points_to_wire<C>), dim3((p.W + 63) / 64), dim3(64), 0, st, cur, b->d_wire_out, (uint32_t)p.W);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(b->ev[3], st));
+  HIP_TRY(hipMemcpyAsync(b->h_wire_out, b->d_wire_out, sizeof(uint64_t) * PWW * (size_t)p.W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  auto t0 = std::chrono::steady_clock::now();
+  horner_host<HC>(b->h_wire_out, p.W, p.c, out);
+  auto t1 = std::chrono::steady_clock::now();
+  float ms;
+  HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1])); g_last_timing[1] = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); g_last_timing[2] = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, b->ev[2], b->ev[3])); g_last_timing[3] = ms;
+  g_last_timing[4] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[3])); g_last_timing[0] = ms + g_last_timing[4];
+  (void)PW;
+  return 0;
+}
+
+}  // namespace
+

@@ -1,0 +1,503 @@
+// Pippenger multi-scalar multiplication kernels for gfx950.
+//
+// Replaces libff::multi_exp_with_mixed_addition<G, Fr, multi_exp_method_BDLO12>
+// (reference: depends/libff/libff/algebra/scalar_multiplication/multiexp.tcc:165-282, :402-496),
+// called from B::multiexp_G1 / B::multiexp_G2 (libsnark/prover_reference_functions.cpp:247-266).
+// The result is the same group element; the schedule is GPU-native:
+//
+//   k_bases_to_internal   wire affine bases -> device form (27x28-bit limbs, R'=2^756), once per base set
+//   k_scalar_digits       Montgomery scalar -> integer (as_bigint), signed radix-2^c Booth digits,
+//                         per-(window,bucket) histogram
+//   scan                  exclusive prefix sum of the histogram (bucket offsets)
+//   k_scatter             counting-sort point indices by (window, bucket)
+//   k_bucket_accumulate   each lane sums exactly T consecutive sorted entries (perfect SIMD balance for
+//                         ANY digit distribution); whole buckets go straight to the bucket array,
+//                         the first / last partial run of each lane goes to an edge array
+//   k_edge_combine        sums the edge pieces that belong to one bucket
+//   k_bucket_reduce       per window, chunked running sums  sum_b (b+1)*B[b]
+//   k_tree_sum            per window, sums the chunk results
+//   k_points_to_wire      window sums -> wire form (projective, Montgomery R=2^768)
+//   host                  Horner over the windows (W*c doublings -- a serial chain of ~750 group
+//                         operations that one CPU core finishes in ~2 ms; one GPU lane would need 60 ms)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "curve753.cuh"
+
+namespace mnt753 {
+
+constexpr int FPS_WORDS = 28;            // storage words per base-field element (27 limbs + pad), 112 B
+constexpr uint32_t EDGE_NONE = 0xffffffffu;
+
+// ---- storage helpers ---------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void fp_load(Fp<M>& r, const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    uint4 v = q[i];
+    r.l[4 * i] = v.x;
+    r.l[4 * i + 1] = v.y;
+    r.l[4 * i + 2] = v.z;
+    if (4 * i + 3 < NL) r.l[4 * i + 3] = v.w;
+  }
+}
+template <int M>
+__device__ __forceinline__ void fp_store(uint32_t* p, const Fp<M>& a) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    uint4 v;
+    v.x = a.l[4 * i];
+    v.y = a.l[4 * i + 1];
+    v.z = a.l[4 * i + 2];
+    v.w = (4 * i + 3 < NL) ? a.l[4 * i + 3] : 0u;
+    q[i] = v;
+  }
+}
+template <class F>
+__device__ __forceinline__ void e_load(typename F::E& r, const uint32_t* p) {
+#pragma unroll
+  for (int k = 0; k < F::DEG; ++k) fp_load(F::comp(r, k), p + k * FPS_WORDS);
+}
+template <class F>
+__device__ __forceinline__ void e_store(uint32_t* p, const typename F::E& a) {
+#pragma unroll
+  for (int k = 0; k < F::DEG; ++k) fp_store(p + k * FPS_WORDS, F::comp(a, k));
+}
+template <class C>
+constexpr int aff_words() { return 2 * C::F::DEG * FPS_WORDS; }
+template <class C>
+constexpr int proj_words() { return 3 * C::F::DEG * FPS_WORDS; }
+template <class C>
+constexpr int wire_coord_words() { return 24 * C::F::DEG; }
+
+template <class C>
+__device__ __forceinline__ void proj_load(Proj<C>& P, const uint32_t* p) {
+  e_load<typename C::F>(P.X, p);
+  e_load<typename C::F>(P.Y, p + C::F::DEG * FPS_WORDS);
+  e_load<typename C::F>(P.Z, p + 2 * C::F::DEG * FPS_WORDS);
+}
+template <class C>
+__device__ __forceinline__ void proj_store(uint32_t* p, const Proj<C>& P) {
+  e_store<typename C::F>(p, P.X);
+  e_store<typename C::F>(p + C::F::DEG * FPS_WORDS, P.Y);
+  e_store<typename C::F>(p + 2 * C::F::DEG * FPS_WORDS, P.Z);
+}
+
+__device__ __forceinline__ void load_wire24(uint32_t w[24], const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    uint4 v = q[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+}
+__device__ __forceinline__ void store_wire24(uint32_t* p, const uint32_t w[24]) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// ---- base conversion ------------------------------------------------------------------------
+// wire affine (x then y, each DEG x 12 u64 little-endian Montgomery R=2^768; y == 0 encodes the
+// identity, libsnark/serialization.hpp:84-111) -> device affine + identity flag
+template <class C>
+__global__ void __launch_bounds__(256) k_bases_to_internal(const uint32_t* __restrict__ wire, uint32_t* __restrict__ out,
+                                                          uint8_t* __restrict__ inf, size_t n) {
+  using F = typename C::F;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* src = wire + i * 2 * wire_coord_words<C>();
+  uint32_t* dst = out + i * aff_words<C>();
+  uint32_t yor = 0;
+#pragma unroll 1
+  for (int k = 0; k < 2 * F::DEG; ++k) {
+    uint32_t w[24];
+    load_wire24(w, src + 24 * k);
+    if (k >= F::DEG) {
+#pragma unroll
+      for (int j = 0; j < 24; ++j) yor |= w[j];
+    }
+    Fp<F::MOD> v;
+    fp_from_wire(v, w);
+    fp_store(dst + k * FPS_WORDS, v);
+  }
+  inf[i] = (yor == 0) ? 1 : 0;
+}
+
+// ---- scalars -> signed digits + histogram -----------------------------------------------------
+// digit w of integer s (radix 2^c, Booth): d = s[cw .. cw+c) + s[cw-1] - 2^c * s[cw+c-1], |d| <= 2^(c-1)
+__device__ __forceinline__ uint32_t lds_bits(const uint32_t* sw, int stride, int pos, int n) {
+  // bits [pos, pos+n) of the 768-bit integer whose word j is sw[j*stride]; n <= 25
+  if (pos >= 768) return 0;
+  int wi = pos >> 5, sh = pos & 31;
+  uint64_t lo = sw[wi * stride];
+  uint64_t hi = (wi + 1 < 24) ? sw[(wi + 1) * stride] : 0u;
+  uint64_t v = (lo | (hi << 32)) >> sh;
+  return (uint32_t)v & ((1u << n) - 1u);
+}
+
+template <int FRM>
+__global__ void __launch_bounds__(256) k_scalar_digits(const uint32_t* __restrict__ scal_wire, const uint8_t* __restrict__ inf,
+                                                      int32_t* __restrict__ digits, uint32_t* __restrict__ hist, size_t n,
+                                                      int c, int W) {
+  __shared__ uint32_t sw[24 * 256];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tid = threadIdx.x;
+  bool live = i < n;
+  if (live) {
+    uint32_t w[24], s[24];
+    load_wire24(w, scal_wire + i * 24);
+    fp_wire_to_integer<FRM>(s, w);
+    if (inf[i]) {
+#pragma unroll
+      for (int j = 0; j < 24; ++j) s[j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 24; ++j) sw[j * 256 + tid] = s[j];
+  }
+  // each lane only reads back its own column: no barrier needed
+  if (!live) return;
+  const uint32_t nb = 1u << (c - 1);
+  for (int w = 0; w < W; ++w) {
+    int pos = w * c;
+    uint32_t win = lds_bits(sw + tid, 256, pos, c);
+    uint32_t blo = pos ? lds_bits(sw + tid, 256, pos - 1, 1) : 0u;
+    uint32_t top = (win >> (c - 1)) & 1u;
+    int32_t d = (int32_t)win + (int32_t)blo - (int32_t)(top << c);
+    digits[(size_t)w * n + i] = d;
+    if (d != 0) {
+      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+      atomicAdd(&hist[(size_t)w * nb + b], 1u);
+    }
+  }
+}
+
+// ---- exclusive scan (three small kernels) ------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wsum[SCAN_THREADS / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  if (wid == 0) {
+    uint32_t s = lane < SCAN_THREADS / 64 ? wsum[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      uint32_t y = __shfl_up(s, o, 64);
+      if (lane >= o) s += y;
+    }
+    if (lane < SCAN_THREADS / 64) wsum[lane] = s;
+  }
+  __syncthreads();
+  uint32_t base = wid ? wsum[wid - 1] : 0;
+  *total = wsum[SCAN_THREADS / 64 - 1];
+  __syncthreads();
+  return base + x - v;
+}
+
+static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                             uint32_t* __restrict__ block_sums, size_t n) {
+  size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0u;
+    s += v[k];
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(s, &total);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < n) out[base + k] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// one block: exclusive scan of up to SCAN_BLOCK block sums, in place; writes the grand total to *total_out
+static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(uint32_t* __restrict__ sums, size_t nblocks, uint32_t* __restrict__ total_out) {
+  size_t base = (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = (base + k < nblocks) ? sums[base + k] : 0u;
+    s += v[k];
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(s, &total);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < nblocks) sums[base + k] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0) *total_out = total;
+}
+
+// offsets[i] += block base; also duplicates into cursor[]; offsets[n] = total
+static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_finish(uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                             const uint32_t* __restrict__ block_sums,
+                                                             const uint32_t* __restrict__ total, size_t n) {
+  size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t add = block_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < n) {
+      uint32_t o = offsets[base + k] + add;
+      offsets[base + k] = o;
+      cursor[base + k] = o;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = *total;
+}
+
+// ---- scatter: counting sort of (point, sign) by flattened bucket id ----------------------------
+static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
+                                                uint32_t* __restrict__ sorted, size_t n, int c, int W) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t nb = 1u << (c - 1);
+  for (int w = 0; w < W; ++w) {
+    int32_t d = digits[(size_t)w * n + i];
+    if (d != 0) {
+      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+      uint32_t pos = atomicAdd(&cursor[(size_t)w * nb + b], 1u);
+      sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
+}
+
+// ---- bucket accumulation ------------------------------------------------------------------------
+// Lane t owns sorted entries [t*T, (t+1)*T).  Runs of equal bucket id inside the segment are summed
+// with mixed additions.  A run that is neither the first nor the last of the segment is a whole
+// bucket -> written to buckets[].  The first and the last run may continue in a neighbouring lane
+// -> written to edges[2t], edges[2t+1] with their bucket ids.
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_bucket_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                             const uint32_t* __restrict__ offsets, uint32_t n_buckets,
+                                                             uint32_t* __restrict__ buckets, uint32_t* __restrict__ edges,
+                                                             uint32_t* __restrict__ edge_bucket, uint32_t T, uint32_t n_lanes) {
+  using F = typename C::F;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_lanes) return;
+  const uint32_t total = offsets[n_buckets];
+  uint64_t e0 = (uint64_t)t * T;
+  if (e0 >= total) {
+    edge_bucket[2 * t] = EDGE_NONE;
+    edge_bucket[2 * t + 1] = EDGE_NONE;
+    return;
+  }
+  uint32_t e = (uint32_t)e0;
+  uint32_t end = (e0 + T < total) ? (uint32_t)(e0 + T) : total;
+  // largest b with offsets[b] <= e  (first x with offsets[x] > e, minus one)
+  uint32_t lo = 0, hi = n_buckets;  // offsets[n_buckets] = total > e
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offsets[mid + 1] > e) hi = mid; else lo = mid + 1;
+  }
+  uint32_t b = lo;
+  uint32_t next = offsets[b + 1];
+  bool first_run = true;
+  bool acc_zero = true;
+  Proj<C> acc, Q;
+  pt_set_zero(acc);
+  F::one(Q.Z);
+  for (; e < end; ++e) {
+    if (e == next) {
+      // bucket b is finished inside this segment
+      if (first_run) {
+        proj_store<C>(edges + (size_t)(2 * t) * proj_words<C>(), acc);
+        edge_bucket[2 * t] = b;
+        first_run = false;
+      } else {
+        proj_store<C>(buckets + (size_t)b * proj_words<C>(), acc);
+      }
+      acc_zero = true;
+      do { ++b; next = offsets[b + 1]; } while (next == e);
+    }
+    uint32_t s = sorted[e];
+    const uint32_t* src = bases + (size_t)(s & 0x7fffffffu) * aff_words<C>();
+    e_load<F>(Q.X, src);
+    e_load<F>(Q.Y, src + F::DEG * FPS_WORDS);
+    if (s & 0x80000000u) F::neg(Q.Y, Q.Y);
+    int pc = PC_MADD;
+    if (acc_zero) {
+      acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z);
+      acc_zero = false;
+      pc = PC_END;
+    } else if (pt_is_zero(acc)) {  // a run summed to the identity (P + -P): restart from Q
+      acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z);
+      pc = PC_END;
+    }
+    pt_vm<C, false>(acc, Q, pc);
+  }
+  // last run of the segment
+  if (first_run) {
+    proj_store<C>(edges + (size_t)(2 * t) * proj_words<C>(), acc);
+    edge_bucket[2 * t] = b;
+    edge_bucket[2 * t + 1] = EDGE_NONE;
+  } else {
+    proj_store<C>(edges + (size_t)(2 * t + 1) * proj_words<C>(), acc);
+    edge_bucket[2 * t + 1] = b;
+  }
+}
+
+// full projective addition with identity handling, through the VM
+template <class C>
+__device__ __forceinline__ int add_pc(Proj<C>& P, const Proj<C>& Q) {
+  // returns the VM entry point for P += Q after resolving identities in place
+  if (pt_is_zero(Q)) return PC_END;
+  if (pt_is_zero(P)) { P = Q; return PC_END; }
+  return PC_ADD;
+}
+
+// ---- edge combine ----------------------------------------------------------------------------------
+// Edge slots are ordered by bucket id.  The first slot of each bucket ("leader") sums the following
+// slots of the same bucket and writes buckets[b].
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_edge_combine(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
+                                                        uint32_t* __restrict__ buckets, uint32_t n_slots) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_slots) return;
+  const uint32_t b = edge_bucket[j];
+  if (b == EDGE_NONE) return;
+  // previous valid slot (at most one EDGE_NONE can sit between two valid slots)
+  if (j >= 1) {
+    uint32_t pb = edge_bucket[j - 1];
+    if (pb == EDGE_NONE && j >= 2) pb = edge_bucket[j - 2];
+    if (pb == b) return;  // not the leader
+  }
+  Proj<C> acc, Q;
+  proj_load<C>(acc, edges + (size_t)j * proj_words<C>());
+  uint32_t k = j + 1;
+  while (k < n_slots) {
+    uint32_t kb = edge_bucket[k];
+    if (kb == EDGE_NONE) {
+      // a gap: either a lane with a single run, or the tail of the launch
+      if (k + 1 < n_slots && edge_bucket[k + 1] == b) { ++k; continue; }
+      break;
+    }
+    if (kb != b) break;
+    proj_load<C>(Q, edges + (size_t)k * proj_words<C>());
+    int pc = add_pc<C>(acc, Q);
+    pt_vm<C, true>(acc, Q, pc);
+    ++k;
+  }
+  proj_store<C>(buckets + (size_t)b * proj_words<C>(), acc);
+}
+
+// ---- bucket reduction ------------------------------------------------------------------------------
+// One lane per (window, chunk of L buckets): out = sum_{j<L} (k0 + j + 1) * B[k0 + j], k0 = chunk * L.
+// Running sums give  acc = sum (j+1) B[k0+j]  and  run = sum B[k0+j];  k0*run is added by
+// double-and-add.  Every lane executes the same (2L + 2*kbits + 1)-step schedule, so the wave never
+// diverges on the step loop and the kernel has ONE pt_vm call site; run / acc / R live in a small
+// per-lane HBM workspace (3 points, ~1 KB of traffic per ~50 us group operation).
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_bucket_reduce(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
+                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ tmp, uint32_t nb,
+                                                         uint32_t L, uint32_t n_chunks_total, int kbits) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_chunks_total) return;
+  constexpr int PW = proj_words<C>();
+  const uint32_t chunks_per_window = nb / L;
+  const uint32_t w = t / chunks_per_window, ch = t % chunks_per_window;
+  const uint32_t k0 = ch * L;
+  const uint32_t base = w * nb + k0;
+  uint32_t* s_run = tmp + (size_t)t * 2 * PW;
+  uint32_t* s_R = s_run + PW;
+  uint32_t* s_acc = out + (size_t)t * PW;
+  {
+    Proj<C> z;
+    pt_set_zero(z);
+    proj_store<C>(s_run, z);
+    proj_store<C>(s_R, z);
+    proj_store<C>(s_acc, z);
+  }
+  const int n_steps = 2 * (int)L + 2 * kbits + 1;
+  Proj<C> P, Q;
+  pt_set_zero(P);
+  pt_set_zero(Q);
+#pragma nounroll
+  for (int step = 0; step < n_steps; ++step) {
+    uint32_t* dst;
+    const uint32_t* src;
+    int mode;  // 0 = add, 1 = dbl, 2 = skip
+    if (step < 2 * (int)L) {
+      const uint32_t b = base + (L - 1u - (uint32_t)(step >> 1));
+      if ((step & 1) == 0) { dst = s_run; src = buckets + (size_t)b * PW; mode = (offsets[b + 1] != offsets[b]) ? 0 : 2; }
+      else { dst = s_acc; src = s_run; mode = 0; }
+    } else if (step < 2 * (int)L + 2 * kbits) {
+      const int q = step - 2 * (int)L;
+      const int bit = kbits - 1 - (q >> 1);
+      dst = s_R;
+      src = s_run;
+      if ((q & 1) == 0) mode = 1;
+      else mode = ((k0 >> bit) & 1u) ? 0 : 2;
+    } else {
+      dst = s_acc; src = s_R; mode = 0;
+    }
+    int pc = PC_END;
+    if (mode != 2) {
+      proj_load<C>(P, dst);
+      if (mode == 0) {
+        proj_load<C>(Q, src);
+        pc = add_pc<C>(P, Q);
+      } else {
+        pc = pt_is_zero(P) ? PC_END : PC_DBL;
+      }
+    }
+    pt_vm<C, true>(P, Q, pc);
+    if (mode != 2) proj_store<C>(dst, P);
+  }
+}
+
+// ---- per-window tree sum ----------------------------------------------------------------------------
+// in: [W][n_in] points, out: [W][n_out], n_out = ceil(n_in / R); lane sums R consecutive points
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_tree_sum(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t W,
+                                                    uint32_t n_in, uint32_t n_out, uint32_t R) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= W * n_out) return;
+  const uint32_t w = t / n_out, o = t % n_out;
+  const uint32_t first = o * R;
+  uint32_t last = first + R;
+  if (last > n_in) last = n_in;
+  Proj<C> acc, Q;
+  proj_load<C>(acc, in + ((size_t)w * n_in + first) * proj_words<C>());
+  for (uint32_t k = first + 1; k < last; ++k) {
+    proj_load<C>(Q, in + ((size_t)w * n_in + k) * proj_words<C>());
+    int pc = add_pc<C>(acc, Q);
+    pt_vm<C, true>(acc, Q, pc);
+  }
+  proj_store<C>(out + ((size_t)w * n_out + o) * proj_words<C>(), acc);
+}
+
+// ---- device form -> wire form (projective; identity is written as (0, 1, 0)) ----------------------------
+template <class C>
+__global__ void __launch_bounds__(64) k_points_to_wire(const uint32_t* __restrict__ in, uint32_t* __restrict__ out_wire, uint32_t n) {
+  using F = typename C::F;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Proj<C> P;
+  proj_load<C>(P, in + (size_t)t * proj_words<C>());
+  if (pt_is_zero(P)) pt_set_zero(P);
+  uint32_t* dst = out_wire + (size_t)t * 3 * wire_coord_words<C>();
+#pragma unroll 1
+  for (int k = 0; k < 3 * F::DEG; ++k) {
+    const typename F::E& coord = (k / F::DEG == 0) ? P.X : ((k / F::DEG == 1) ? P.Y : P.Z);
+    uint32_t w[24];
+    fp_to_wire(w, F::comp(coord, k % F::DEG));
+    store_wire24(dst + 24 * k, w);
+  }
+}
+
+}  // namespace mnt753

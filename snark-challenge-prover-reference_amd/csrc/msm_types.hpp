@@ -1,0 +1,36 @@
+// Plain host-side types shared by the MSM translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mnt753 {
+struct MsmPlan {
+  int c, W;
+  uint32_t nb;        // buckets per window = 2^(c-1)
+  uint32_t n_buckets; // W * nb
+  uint32_t T;         // sorted entries per accumulate lane
+  uint32_t n_lanes;   // accumulate lanes
+  uint32_t L;         // buckets per reduce lane
+  uint32_t n_chunks;  // W * nb / L
+};
+}  // namespace mnt753
+
+struct mnt753_bases {
+  int curve, group;
+  size_t n;
+  uint32_t* d_aff = nullptr;   // device affine, internal form
+  uint8_t* d_inf = nullptr;    // identity flags
+  // workspace (sized for an MSM over all n bases; reused by every call)
+  size_t ws_n = 0;
+  mnt753::MsmPlan ws_plan{};
+  int32_t* d_digits = nullptr;
+  uint32_t *d_hist = nullptr, *d_offsets = nullptr, *d_cursor = nullptr, *d_blocksums = nullptr, *d_total = nullptr;
+  uint32_t* d_sorted = nullptr;
+  uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr;
+  uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;
+  uint32_t* d_wire_out = nullptr;
+  uint64_t* h_wire_out = nullptr;   // pinned
+  uint64_t* d_scalars_stage = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
