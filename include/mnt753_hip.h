@@ -122,6 +122,15 @@ int mnt753_vec_subeq(int curve, uint64_t* dev_a, const uint64_t* dev_b, size_t n
 int mnt753_compute_h(mnt753_domain* d, uint64_t* dev_ca, uint64_t* dev_cb, uint64_t* dev_cc, uint64_t* dev_h,
                      void* stream);
 
+/* ---- deterministic synthetic inputs (host) ---------------------------------------------------------
+ * Stand-in for libsnark/generate_parameters.cpp on machines that have neither the reference nor its
+ * parameter files: bases with known discrete logarithms base[k] = e_k * G, uniform scalars, and the exact
+ * value of sum scalars[k] * base[k] computed from the e_k (one scalar multiplication) for parity checks
+ * at sizes no CPU implementation finishes quickly. */
+int mnt753_synth_points(int curve, int group, uint64_t seed, size_t n, uint64_t* out_affine, int threads);
+int mnt753_synth_scalars(int curve, uint64_t seed, size_t n, uint64_t* out_scalars);
+int mnt753_synth_expected_msm(int curve, int group, uint64_t seed, size_t n, const uint64_t* scalars, uint64_t* out_projective);
+
 #ifdef __cplusplus
 }
 #endif

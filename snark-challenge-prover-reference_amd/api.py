@@ -59,6 +59,9 @@ def lib():
         "mnt753_vec_muleq": (i, [i, vp, vp, sz, vp]),
         "mnt753_vec_subeq": (i, [i, vp, vp, sz, vp]),
         "mnt753_compute_h": (i, [vp, vp, vp, vp, vp, vp]),
+        "mnt753_synth_points": (i, [i, i, C.c_uint64, sz, u64p, i]),
+        "mnt753_synth_scalars": (i, [i, C.c_uint64, sz, u64p]),
+        "mnt753_synth_expected_msm": (i, [i, i, C.c_uint64, sz, u64p, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = the library does not export what the header declares
@@ -240,3 +243,23 @@ def vec_muleq(curve, a_ptr, b_ptr, n, stream=None):
 def vec_subeq(curve, a_ptr, b_ptr, n, stream=None):
     st = C.c_void_p(int(stream)) if stream else C.c_void_p()
     _check(lib().mnt753_vec_subeq(curve, C.c_void_p(int(a_ptr)), C.c_void_p(int(b_ptr)), n, st), "mnt753_vec_subeq")
+
+
+def synth_points(curve, group, seed, n, threads=None):
+    out = np.zeros((n, affine_words(curve, group)), dtype=np.uint64)
+    threads = threads or min(64, os.cpu_count() or 1)
+    _check(lib().mnt753_synth_points(curve, group, seed, n, out.ctypes.data_as(C.POINTER(C.c_uint64)), threads), "mnt753_synth_points")
+    return out
+
+
+def synth_scalars(curve, seed, n):
+    out = np.zeros((n, 12), dtype=np.uint64)
+    _check(lib().mnt753_synth_scalars(curve, seed, n, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_synth_scalars")
+    return out
+
+
+def synth_expected_msm(curve, group, seed, scalars):
+    s, ps = _u64(scalars)
+    out = np.zeros(projective_words(curve, group), dtype=np.uint64)
+    _check(lib().mnt753_synth_expected_msm(curve, group, seed, s.size // 12, ps, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_synth_expected_msm")
+    return out

@@ -71,10 +71,11 @@ int proj_w() { return proj_words<C>(); }
 
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
-                  b->d_edges, b->d_edge_bucket, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage};
+                  b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
   b->d_digits = nullptr; b->d_hist = b->d_offsets = b->d_cursor = b->d_blocksums = b->d_total = nullptr;
+  b->d_edge_tmp = b->d_edge_flags = nullptr;
   b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
   b->h_wire_out = nullptr; b->d_scalars_stage = nullptr;
   b->ws_n = 0;
@@ -96,6 +97,8 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_buckets, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_edges, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_bucket, sizeof(uint32_t) * 2 * (size_t)p.n_lanes));
+  HIP_TRY(hipMalloc(&b->d_edge_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
+  HIP_TRY(hipMalloc(&b->d_edge_flags, sizeof(uint32_t) * 40));
   HIP_TRY(hipMalloc(&b->d_part_a, sizeof(uint32_t) * PW * (size_t)p.n_chunks));
   HIP_TRY(hipMalloc(&b->d_part_b, sizeof(uint32_t) * PW * ((size_t)p.n_chunks / 2 + (size_t)p.W)));
   HIP_TRY(hipMalloc(&b->d_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_chunks));
@@ -177,8 +180,19 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
   hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
                      p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
   HIP_TRY(hipEventRecord(b->ev[2], st));
-  hipLaunchKernelGGL((k_edge_combine<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_edges, b->d_edge_bucket,
-                     b->d_buckets, 2 * p.n_lanes);
+  {
+    const uint32_t n_slots = 2 * p.n_lanes;
+    const unsigned gs = (n_slots + 255) / 256;
+    HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));
+    uint32_t level = 0;
+    for (uint32_t dist = 1; dist < n_slots; dist <<= 1, ++level) {
+      hipLaunchKernelGGL((k_edge_level_sum<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
+                         b->d_edge_flags, level);
+      hipLaunchKernelGGL((k_edge_level_copy<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
+                         b->d_edge_flags, level);
+    }
+    hipLaunchKernelGGL((k_edge_finish<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_buckets, n_slots);
+  }
   hipLaunchKernelGGL((k_bucket_reduce<C>), dim3((p.n_chunks + 255) / 256), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,
                      b->d_tmp, p.nb, p.L, p.n_chunks, p.c - 1);
   // tree: [W][n_in] -> [W][1]

@@ -125,6 +125,35 @@ __global__ void __launch_bounds__(256) k_bases_to_internal(const uint32_t* __res
   inf[i] = (yor == 0) ? 1 : 0;
 }
 
+// ---- wave-aggregated atomics ---------------------------------------------------------------------------
+// Digit distributions are skewed where it matters: the top window of a 753-bit scalar only takes the values
+// {0,1,2}, and real witnesses repeat scalars.  Up to AGG_ROUNDS times, the lanes that share the bucket of
+// the first pending lane issue ONE atomic for the whole group; whatever is left falls back to per-lane
+// atomics (the uniform-digit case, where almost every lane has its own bucket).
+constexpr int AGG_ROUNDS = 3;
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// returns the value of counter[key] before this lane's increment (lanes with !active return 0)
+__device__ __forceinline__ uint32_t wave_atomic_inc(uint32_t* counter, uint32_t key, bool active) {
+  uint32_t result = 0;
+  unsigned long long pending = __ballot(active);
+  const uint32_t lane = lane_id();
+#pragma unroll 1
+  for (int r = 0; r < AGG_ROUNDS && pending; ++r) {
+    const int leader = __ffsll((long long)pending) - 1;
+    const uint32_t lkey = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+    const bool mine = active && key == lkey && ((pending >> lane) & 1ull);
+    const unsigned long long grp = __ballot(mine);
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&counter[lkey], (uint32_t)__popcll(grp));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if (mine) result = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+    pending &= ~grp;
+  }
+  if (active && ((pending >> lane) & 1ull)) result = atomicAdd(&counter[key], 1u);
+  return result;
+}
+
 // ---- scalars -> signed digits + histogram -----------------------------------------------------
 // digit w of integer s (radix 2^c, Booth): d = s[cw .. cw+c) + s[cw-1] - 2^c * s[cw+c-1], |d| <= 2^(c-1)
 __device__ __forceinline__ uint32_t lds_bits(const uint32_t* sw, int stride, int pos, int n) {
@@ -156,20 +185,20 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint32_t* __restric
 #pragma unroll
     for (int j = 0; j < 24; ++j) sw[j * 256 + tid] = s[j];
   }
-  // each lane only reads back its own column: no barrier needed
-  if (!live) return;
+  // each lane only reads back its own column: no barrier needed; dead lanes keep taking part in the ballots
   const uint32_t nb = 1u << (c - 1);
   for (int w = 0; w < W; ++w) {
-    int pos = w * c;
-    uint32_t win = lds_bits(sw + tid, 256, pos, c);
-    uint32_t blo = pos ? lds_bits(sw + tid, 256, pos - 1, 1) : 0u;
-    uint32_t top = (win >> (c - 1)) & 1u;
-    int32_t d = (int32_t)win + (int32_t)blo - (int32_t)(top << c);
-    digits[(size_t)w * n + i] = d;
-    if (d != 0) {
-      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-      atomicAdd(&hist[(size_t)w * nb + b], 1u);
+    int32_t d = 0;
+    if (live) {
+      int pos = w * c;
+      uint32_t win = lds_bits(sw + tid, 256, pos, c);
+      uint32_t blo = pos ? lds_bits(sw + tid, 256, pos - 1, 1) : 0u;
+      uint32_t top = (win >> (c - 1)) & 1u;
+      d = (int32_t)win + (int32_t)blo - (int32_t)(top << c);
+      digits[(size_t)w * n + i] = d;
     }
+    uint32_t b = d ? (uint32_t)(d < 0 ? -d : d) - 1u : 0u;
+    wave_atomic_inc(hist + (size_t)w * nb, b, d != 0);
   }
 }
 
@@ -264,15 +293,13 @@ static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_finish(uint32_t* _
 static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
                                                 uint32_t* __restrict__ sorted, size_t n, int c, int W) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
   const uint32_t nb = 1u << (c - 1);
   for (int w = 0; w < W; ++w) {
-    int32_t d = digits[(size_t)w * n + i];
-    if (d != 0) {
-      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-      uint32_t pos = atomicAdd(&cursor[(size_t)w * nb + b], 1u);
-      sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
-    }
+    int32_t d = live ? digits[(size_t)w * n + i] : 0;
+    uint32_t b = d ? (uint32_t)(d < 0 ? -d : d) - 1u : 0u;
+    uint32_t pos = wave_atomic_inc(cursor + (size_t)w * nb, b, d != 0);
+    if (d != 0) sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
   }
 }
 
@@ -344,7 +371,10 @@ __global__ void __launch_bounds__(256, 1) k_bucket_accumulate(const uint32_t* __
   if (first_run) {
     proj_store<C>(edges + (size_t)(2 * t) * proj_words<C>(), acc);
     edge_bucket[2 * t] = b;
-    edge_bucket[2 * t + 1] = EDGE_NONE;
+    // single-run lane: the second slot is an identity piece of the same bucket (keeps the slot list gap-free)
+    pt_set_zero(acc);
+    proj_store<C>(edges + (size_t)(2 * t + 1) * proj_words<C>(), acc);
+    edge_bucket[2 * t + 1] = b;
   } else {
     proj_store<C>(edges + (size_t)(2 * t + 1) * proj_words<C>(), acc);
     edge_bucket[2 * t + 1] = b;
@@ -361,38 +391,56 @@ __device__ __forceinline__ int add_pc(Proj<C>& P, const Proj<C>& Q) {
 }
 
 // ---- edge combine ----------------------------------------------------------------------------------
-// Edge slots are ordered by bucket id.  The first slot of each bucket ("leader") sums the following
-// slots of the same bucket and writes buckets[b].
+// Edge slots are ordered by bucket id (EDGE_NONE only at the tail).  The pieces of one bucket form a run of
+// consecutive slots; runs are reduced to their first slot by pointer jumping: at level s every slot adds
+// the slot 2^s further on if it belongs to the same bucket.  Depth is log2(longest run) for ANY digit
+// distribution (the top window alone produces runs of ~N/(2T) pieces).  Each level is two tiny kernels
+// (sum into tmp, copy back) so that no slot is read while it is rewritten; a device flag lets the levels
+// after the last useful one exit at once.
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_edge_combine(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
-                                                        uint32_t* __restrict__ buckets, uint32_t n_slots) {
+__global__ void __launch_bounds__(256, 1) k_edge_level_sum(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
+                                                          uint32_t* __restrict__ tmp, uint32_t n_slots, uint32_t dist,
+                                                          uint32_t* __restrict__ flags, uint32_t level) {
+  if (level > 0 && flags[level - 1] == 0) return;   // no run longer than dist/1: nothing left to do
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_slots || j + dist >= n_slots) return;
+  const uint32_t b = edge_bucket[j];
+  if (b == EDGE_NONE || edge_bucket[j + dist] != b) return;
+  Proj<C> acc, Q;
+  proj_load<C>(acc, edges + (size_t)j * proj_words<C>());
+  proj_load<C>(Q, edges + (size_t)(j + dist) * proj_words<C>());
+  int pc = add_pc<C>(acc, Q);
+  pt_vm<C, true>(acc, Q, pc);
+  proj_store<C>(tmp + (size_t)j * proj_words<C>(), acc);
+  flags[level] = 1;
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_edge_level_copy(uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
+                                                        const uint32_t* __restrict__ tmp, uint32_t n_slots, uint32_t dist,
+                                                        const uint32_t* __restrict__ flags, uint32_t level) {
+  if (flags[level] == 0) return;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_slots || j + dist >= n_slots) return;
+  const uint32_t b = edge_bucket[j];
+  if (b == EDGE_NONE || edge_bucket[j + dist] != b) return;
+  const uint4* src = reinterpret_cast<const uint4*>(tmp + (size_t)j * proj_words<C>());
+  uint4* dst = reinterpret_cast<uint4*>(edges + (size_t)j * proj_words<C>());
+#pragma unroll
+  for (int k = 0; k < proj_words<C>() / 4; ++k) dst[k] = src[k];
+}
+// the first slot of every run now holds the bucket's sum
+template <class C>
+__global__ void __launch_bounds__(256) k_edge_finish(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
+                                                    uint32_t* __restrict__ buckets, uint32_t n_slots) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_slots) return;
   const uint32_t b = edge_bucket[j];
   if (b == EDGE_NONE) return;
-  // previous valid slot (at most one EDGE_NONE can sit between two valid slots)
-  if (j >= 1) {
-    uint32_t pb = edge_bucket[j - 1];
-    if (pb == EDGE_NONE && j >= 2) pb = edge_bucket[j - 2];
-    if (pb == b) return;  // not the leader
-  }
-  Proj<C> acc, Q;
-  proj_load<C>(acc, edges + (size_t)j * proj_words<C>());
-  uint32_t k = j + 1;
-  while (k < n_slots) {
-    uint32_t kb = edge_bucket[k];
-    if (kb == EDGE_NONE) {
-      // a gap: either a lane with a single run, or the tail of the launch
-      if (k + 1 < n_slots && edge_bucket[k + 1] == b) { ++k; continue; }
-      break;
-    }
-    if (kb != b) break;
-    proj_load<C>(Q, edges + (size_t)k * proj_words<C>());
-    int pc = add_pc<C>(acc, Q);
-    pt_vm<C, true>(acc, Q, pc);
-    ++k;
-  }
-  proj_store<C>(buckets + (size_t)b * proj_words<C>(), acc);
+  if (j > 0 && edge_bucket[j - 1] == b) return;
+  const uint4* src = reinterpret_cast<const uint4*>(edges + (size_t)j * proj_words<C>());
+  uint4* dst = reinterpret_cast<uint4*>(buckets + (size_t)b * proj_words<C>());
+#pragma unroll
+  for (int k = 0; k < proj_words<C>() / 4; ++k) dst[k] = src[k];
 }
 
 // ---- bucket reduction ------------------------------------------------------------------------------

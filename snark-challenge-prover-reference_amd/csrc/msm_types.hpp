@@ -27,7 +27,7 @@ struct mnt753_bases {
   int32_t* d_digits = nullptr;
   uint32_t *d_hist = nullptr, *d_offsets = nullptr, *d_cursor = nullptr, *d_blocksums = nullptr, *d_total = nullptr;
   uint32_t* d_sorted = nullptr;
-  uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr;
+  uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr, *d_edge_tmp = nullptr, *d_edge_flags = nullptr;
   uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;
   uint32_t* d_wire_out = nullptr;
   uint64_t* h_wire_out = nullptr;   // pinned
