@@ -1,0 +1,92 @@
+"""ctypes face of oracle/liboracle.so (the CPU oracle).  TEST INFRASTRUCTURE: imported by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        L = C.CDLL(path)
+        u64p, sz, i = C.POINTER(C.c_uint64), C.c_size_t, C.c_int
+        L.oracle_field_op.argtypes = [i, i, u64p, u64p, u64p]
+        L.oracle_point_op.argtypes = [i, i, i, u64p, u64p, u64p]
+        L.oracle_msm.argtypes = [i, i, u64p, u64p, sz, sz, u64p]
+        L.oracle_fft.argtypes = [i, i, u64p, sz]
+        L.oracle_divide_by_z_on_coset.argtypes = [i, u64p, sz]
+        L.oracle_compute_h.argtypes = [i, u64p, u64p, u64p, u64p, sz]
+        L.oracle_prove.argtypes = [i, C.c_char_p, C.c_char_p, C.c_char_p, sz, C.POINTER(C.c_double)]
+        L.oracle_max_threads.restype = i
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _arr(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def aff_words(curve, group):
+    return 24 * (1 if group == 1 else (2 if curve == 0 else 3))
+
+
+def field_op(mod, op, a, b=None):
+    a = _arr(a); out = np.zeros(12, dtype=np.uint64)
+    bb = _arr(b) if b is not None else np.zeros(12, dtype=np.uint64)
+    assert lib().oracle_field_op(mod, op, _p(a), _p(bb), _p(out)) == 0
+    return out
+
+
+def point_op(curve, group, op, p, q=None):
+    p = _arr(p); out = np.zeros(aff_words(curve, group), dtype=np.uint64)
+    qq = _arr(q) if q is not None else np.zeros(max(12, aff_words(curve, group)), dtype=np.uint64)
+    assert lib().oracle_point_op(curve, group, op, _p(p), _p(qq), _p(out)) == 0
+    return out
+
+
+def msm(curve, group, bases, scalars, chunks=1):
+    bases = _arr(bases); scalars = _arr(scalars)
+    n = scalars.size // 12
+    out = np.zeros(aff_words(curve, group), dtype=np.uint64)
+    assert lib().oracle_msm(curve, group, _p(bases), _p(scalars), n, chunks, _p(out)) == 0
+    return out
+
+
+def fft(curve, kind, vec):
+    v = _arr(vec).copy()
+    assert lib().oracle_fft(curve, kind, _p(v), v.size // 12) == 0
+    return v
+
+
+def divide_by_z_on_coset(curve, vec):
+    v = _arr(vec).copy()
+    assert lib().oracle_divide_by_z_on_coset(curve, _p(v), v.size // 12) == 0
+    return v
+
+
+def compute_h(curve, ca, cb, cc):
+    ca, cb, cc = _arr(ca).copy(), _arr(cb).copy(), _arr(cc).copy()
+    m = ca.size // 12
+    h = np.zeros((m + 1) * 12, dtype=np.uint64)
+    assert lib().oracle_compute_h(curve, _p(ca), _p(cb), _p(cc), _p(h), m) == 0
+    return h
+
+
+def prove(curve, params, inp, out, chunks=None):
+    t = (C.c_double * 4)()
+    chunks = chunks or lib().oracle_max_threads()
+    rc = lib().oracle_prove(curve, params.encode(), inp.encode(), out.encode(), chunks, t)
+    assert rc == 0, rc
+    return list(t)
