@@ -11,7 +11,13 @@ HIP_SRCS := mnt753_core.hip mnt753_msm.hip msm_inst_mnt4g1.hip msm_inst_mnt4g2.h
 HIP_OBJS := $(addprefix $(BUILD)/,$(HIP_SRCS:.hip=.o))
 HDRS := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.cuh $(CSRC)/*.h include/*.h)
 
-all: $(LIB) oracle
+HOST := $(PKG)/host
+MAIN := $(PKG)/main_hip
+
+all: $(LIB) $(MAIN) oracle
+
+$(MAIN): $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp include/prover_hip_functions.hpp include/mnt753_hip.h $(LIB)
+	g++ -O2 -std=c++17 -o $@ $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp -L$(PKG) -lmnt753_hip -Wl,-rpath,'$$ORIGIN'
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -24,7 +30,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf $(BUILD) $(LIB)
+	rm -rf $(BUILD) $(LIB) $(MAIN)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,259 @@
+// Implementation of include/prover_hip_functions.hpp on top of the C ABI (include/mnt753_hip.h).
+// Counterpart of the reference's libsnark/prover_reference_functions.cpp (662 lines of libff/libfqfft calls):
+// here every vector lives in HBM and every heavy call is a HIP kernel launch.
+#include "../../include/prover_hip_functions.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mnt753_hip.h"
+
+namespace mnt753_hip_detail {
+
+[[noreturn]] static void fail(const char* what) {
+  throw std::runtime_error(std::string(what) + ": " + mnt753_last_error());
+}
+static void check(int rc, const char* what) { if (rc != 0) fail(what); }
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  explicit DeviceBuffer(size_t n) : bytes(n) { check(mnt753_dev_alloc(&ptr, n), "mnt753_dev_alloc"); }
+  ~DeviceBuffer() { if (ptr) mnt753_dev_free(ptr); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+};
+struct BaseSetHolder {
+  mnt753_bases* h = nullptr;
+  ~BaseSetHolder() { if (h) mnt753_bases_free(h); }
+};
+struct DomainHolder {
+  mnt753_domain* h = nullptr;
+  ~DomainHolder() { if (h) mnt753_domain_free(h); }
+};
+
+static void read_exact(FILE* f, void* dst, size_t bytes, const char* path) {
+  if (bytes && fread(dst, 1, bytes, f) != bytes) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
+}
+}  // namespace mnt753_hip_detail
+
+using namespace mnt753_hip_detail;
+
+template <int CURVE> struct mnt753_hip_impl<CURVE>::evaluation_domain { std::shared_ptr<DomainHolder> data; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::field { uint64_t data[12]; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::G1 { uint64_t data[36]; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::G2 { uint64_t data[108]; };  // 72 used on MNT4753, 108 on MNT6753
+template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
+  std::shared_ptr<DeviceBuffer> data;
+  size_t size;     // elements in the underlying buffer
+  size_t offset;   // element offset honoured by multiexp / muleq / subeq (prover_reference_functions.cpp:173,254)
+  uint64_t* ptr() const { return reinterpret_cast<uint64_t*>(data->ptr) + 12 * offset; }
+};
+template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G1 { std::shared_ptr<BaseSetHolder> data; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G2 { std::shared_ptr<BaseSetHolder> data; };
+
+// params file: u64 d, u64 m, A[m+1] G1, B1[m+1] G1, B2[m+1] G2, L[m-1] G1, H[d] G1
+// (libsnark/generate_parameters.cpp:60-85, reader prover_reference_functions.cpp:86-116)
+template <int CURVE>
+class mnt753_hip_impl<CURVE>::groth16_params {
+public:
+  size_t d = 0, m = 0;
+  std::shared_ptr<BaseSetHolder> A, B1, L, H, B2;
+  explicit groth16_params(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open params file ") + path);
+    uint64_t dm[2];
+    read_exact(f, dm, 16, path);
+    d = dm[0]; m = dm[1];
+    const size_t g1w = mnt753_affine_words(CURVE, MNT753_G1), g2w = mnt753_affine_words(CURVE, MNT753_G2);
+    auto load = [&](int group, size_t words, size_t n) {
+      std::vector<uint64_t> host(words * n);
+      read_exact(f, host.data(), host.size() * 8, path);
+      auto h = std::make_shared<BaseSetHolder>();
+      check(mnt753_bases_create(CURVE, group, host.data(), 0, n, &h->h), "mnt753_bases_create");
+      return h;
+    };
+    A = load(MNT753_G1, g1w, m + 1);
+    B1 = load(MNT753_G1, g1w, m + 1);
+    B2 = load(MNT753_G2, g2w, m + 1);
+    L = load(MNT753_G1, g1w, m - 1);
+    H = load(MNT753_G1, g1w, d);
+    fclose(f);
+  }
+};
+
+// input file: w[m+1], ca[d+1], cb[d+1], cc[d+1], r   (generate_parameters.cpp:88-108, reader :48-76)
+template <int CURVE>
+class mnt753_hip_impl<CURVE>::groth16_input {
+public:
+  std::shared_ptr<DeviceBuffer> w, ca, cb, cc;
+  size_t n_w = 0, n_c = 0;
+  uint64_t r[12];
+  groth16_input(const char* path, size_t d, size_t m) {
+    FILE* f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open input file ") + path);
+    n_w = m + 1; n_c = d + 1;
+    std::vector<uint64_t> host(12 * (n_w > n_c ? n_w : n_c));
+    auto load = [&](size_t n) {
+      read_exact(f, host.data(), 96 * n, path);
+      auto b = std::make_shared<DeviceBuffer>(96 * n);
+      check(mnt753_copy_h2d(b->ptr, host.data(), 96 * n), "mnt753_copy_h2d");
+      return b;
+    };
+    w = load(n_w); ca = load(n_c); cb = load(n_c); cc = load(n_c);
+    read_exact(f, r, 96, path);
+    fclose(f);
+  }
+};
+
+#define HIP_B mnt753_hip_impl<CURVE>
+
+template <int CURVE> void HIP_B::init_public_params() { check(mnt753_init(0), "mnt753_init"); }
+
+template <int CURVE> void HIP_B::print_G1(G1* a) {
+  uint64_t aff[24];
+  check(mnt753_point_to_affine(CURVE, MNT753_G1, a->data, aff), "mnt753_point_to_affine");
+  printf("G1 affine (Montgomery limbs, little-endian):\n x =");
+  for (int i = 11; i >= 0; --i) printf(" %016llx", (unsigned long long)aff[i]);
+  printf("\n y =");
+  for (int i = 11; i >= 0; --i) printf(" %016llx", (unsigned long long)aff[12 + i]);
+  printf("\n");
+}
+template <int CURVE> void HIP_B::print_G2(G2* a) {
+  const size_t w = mnt753_affine_words(CURVE, MNT753_G2);
+  uint64_t aff[72];
+  check(mnt753_point_to_affine(CURVE, MNT753_G2, a->data, aff), "mnt753_point_to_affine");
+  printf("G2 affine (Montgomery limbs, little-endian), %zu coefficients:\n", w / 12);
+  for (size_t k = 0; k < w / 12; ++k) {
+    printf(" c%zu =", k);
+    for (int i = 11; i >= 0; --i) printf(" %016llx", (unsigned long long)aff[12 * k + i]);
+    printf("\n");
+  }
+}
+
+template <int CURVE> typename HIP_B::evaluation_domain* HIP_B::get_evaluation_domain(size_t d) {
+  auto h = std::make_shared<DomainHolder>();
+  check(mnt753_domain_create(CURVE, d, &h->h), "mnt753_domain_create");
+  return new evaluation_domain{h};
+}
+
+template <int CURVE> typename HIP_B::G1* HIP_B::G1_add(G1* a, G1* b) {
+  G1* r = new G1();
+  check(mnt753_point_add(CURVE, MNT753_G1, a->data, b->data, r->data), "mnt753_point_add");
+  return r;
+}
+template <int CURVE> typename HIP_B::G1* HIP_B::G1_scale(field* a, G1* b) {
+  G1* r = new G1();
+  check(mnt753_point_scale(CURVE, MNT753_G1, a->data, b->data, r->data), "mnt753_point_scale");
+  return r;
+}
+
+template <int CURVE> void HIP_B::vector_Fr_muleq(vector_Fr* a, vector_Fr* b, size_t size) {
+  check(mnt753_vec_muleq(CURVE, a->ptr(), b->ptr(), size, nullptr), "mnt753_vec_muleq");
+}
+template <int CURVE> void HIP_B::vector_Fr_subeq(vector_Fr* a, vector_Fr* b, size_t size) {
+  check(mnt753_vec_subeq(CURVE, a->ptr(), b->ptr(), size, nullptr), "mnt753_vec_subeq");
+}
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_offset(vector_Fr* a, size_t offset) {
+  return new vector_Fr{a->data, a->size, offset};
+}
+template <int CURVE> void HIP_B::vector_Fr_copy_into(vector_Fr* src, vector_Fr* dst, size_t length) {
+  // MNT4753: dst[i] = src[i] ignoring offsets (prover_reference_functions.cpp:209-212);
+  // MNT6753: dst[i] = src[i + src->offset]            (:515-520)
+  const uint64_t* s = reinterpret_cast<const uint64_t*>(src->data->ptr) + (CURVE == 1 ? 12 * src->offset : 0);
+  std::vector<uint64_t> tmp(12 * length);   // D2D through the ABI's two copies keeps the ABI minimal; length <= 2^20
+  check(mnt753_copy_d2h(tmp.data(), s, 96 * length), "mnt753_copy_d2h");
+  check(mnt753_copy_h2d(dst->data->ptr, tmp.data(), 96 * length), "mnt753_copy_h2d");
+}
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_zeros(size_t length) {
+  auto b = std::make_shared<DeviceBuffer>(96 * length);
+  std::vector<uint64_t> z(12 * length, 0);
+  check(mnt753_copy_h2d(b->ptr, z.data(), 96 * length), "mnt753_copy_h2d");
+  return new vector_Fr{b, length, 0};
+}
+
+template <int CURVE> void HIP_B::domain_iFFT(evaluation_domain* domain, vector_Fr* a) {
+  check(mnt753_fft(domain->data->h, MNT753_IFFT, a->ptr(), nullptr), "mnt753_fft(iFFT)");
+}
+template <int CURVE> void HIP_B::domain_cosetFFT(evaluation_domain* domain, vector_Fr* a) {
+  check(mnt753_fft(domain->data->h, MNT753_COSET_FFT, a->ptr(), nullptr), "mnt753_fft(cosetFFT)");
+}
+template <int CURVE> void HIP_B::domain_icosetFFT(evaluation_domain* domain, vector_Fr* a) {
+  check(mnt753_fft(domain->data->h, MNT753_ICOSET_FFT, a->ptr(), nullptr), "mnt753_fft(icosetFFT)");
+}
+template <int CURVE> void HIP_B::domain_divide_by_Z_on_coset(evaluation_domain* domain, vector_Fr* a) {
+  check(mnt753_divide_by_z_on_coset(domain->data->h, a->ptr(), nullptr), "mnt753_divide_by_z_on_coset");
+}
+template <int CURVE> size_t HIP_B::domain_get_m(evaluation_domain* domain) { return mnt753_domain_size(domain->data->h); }
+
+template <int CURVE> typename HIP_B::G1* HIP_B::multiexp_G1(vector_Fr* scalar_start, vector_G1* g_start, size_t length) {
+  G1* r = new G1();
+  check(mnt753_msm(g_start->data->h, 0, scalar_start->ptr(), 1, length, r->data, nullptr), "mnt753_msm(G1)");
+  return r;
+}
+template <int CURVE> typename HIP_B::G2* HIP_B::multiexp_G2(vector_Fr* scalar_start, vector_G2* g_start, size_t length) {
+  G2* r = new G2();
+  check(mnt753_msm(g_start->data->h, 0, scalar_start->ptr(), 1, length, r->data, nullptr), "mnt753_msm(G2)");
+  return r;
+}
+
+template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_input(const char* path, groth16_params* params) {
+  return new groth16_input(path, params->d, params->m);
+}
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_w(groth16_input* in) { return new vector_Fr{in->w, in->n_w, 0}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_ca(groth16_input* in) { return new vector_Fr{in->ca, in->n_c, 0}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cb(groth16_input* in) { return new vector_Fr{in->cb, in->n_c, 0}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cc(groth16_input* in) { return new vector_Fr{in->cc, in->n_c, 0}; }
+template <int CURVE> typename HIP_B::field* HIP_B::input_r(groth16_input* in) {
+  field* f = new field();
+  memcpy(f->data, in->r, 96);
+  return f;
+}
+
+template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const char* path) { return new groth16_params(path); }
+template <int CURVE> size_t HIP_B::params_d(groth16_params* p) { return p->d; }
+template <int CURVE> size_t HIP_B::params_m(groth16_params* p) { return p->m; }
+template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_A(groth16_params* p) { return new vector_G1{p->A}; }
+template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_B1(groth16_params* p) { return new vector_G1{p->B1}; }
+template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_L(groth16_params* p) { return new vector_G1{p->L}; }
+template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_H(groth16_params* p) { return new vector_G1{p->H}; }
+template <int CURVE> typename HIP_B::vector_G2* HIP_B::params_B2(groth16_params* p) { return new vector_G2{p->B2}; }
+
+template <int CURVE> void HIP_B::delete_G1(G1* a) { delete a; }
+template <int CURVE> void HIP_B::delete_G2(G2* a) { delete a; }
+template <int CURVE> void HIP_B::delete_vector_Fr(vector_Fr* a) { delete a; }
+template <int CURVE> void HIP_B::delete_vector_G1(vector_G1* a) { delete a; }
+template <int CURVE> void HIP_B::delete_vector_G2(vector_G2* a) { delete a; }
+template <int CURVE> void HIP_B::delete_groth16_input(groth16_input* a) { delete a; }
+template <int CURVE> void HIP_B::delete_groth16_params(groth16_params* a) { delete a; }
+template <int CURVE> void HIP_B::delete_evaluation_domain(evaluation_domain* a) { delete a; }
+
+// write_g1(A) write_g2(B) write_g1(C)   (prover_reference_functions.cpp:347-356, serialization.hpp:44-67)
+template <int CURVE> void HIP_B::groth16_output_write(G1* A, G2* B, G1* C, const char* output_path) {
+  const size_t g2w = mnt753_affine_words(CURVE, MNT753_G2);
+  uint64_t a[24], b[72], c[24];
+  check(mnt753_point_to_affine(CURVE, MNT753_G1, A->data, a), "mnt753_point_to_affine(A)");
+  check(mnt753_point_to_affine(CURVE, MNT753_G2, B->data, b), "mnt753_point_to_affine(B)");
+  check(mnt753_point_to_affine(CURVE, MNT753_G1, C->data, c), "mnt753_point_to_affine(C)");
+  FILE* out = fopen(output_path, "wb");
+  if (!out) throw std::runtime_error(std::string("cannot open output file ") + output_path);
+  fwrite(a, 8, 24, out);
+  fwrite(b, 8, g2w, out);
+  fwrite(c, 8, 24, out);
+  fclose(out);
+}
+
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::compute_H_fused(evaluation_domain* domain, vector_Fr* ca, vector_Fr* cb, vector_Fr* cc) {
+  const size_t m = mnt753_domain_size(domain->data->h);
+  auto h = std::make_shared<DeviceBuffer>(96 * (m + 1));
+  check(mnt753_compute_h(domain->data->h, ca->ptr(), cb->ptr(), cc->ptr(), reinterpret_cast<uint64_t*>(h->ptr), nullptr), "mnt753_compute_h");
+  return new vector_Fr{h, m + 1, 0};
+}
+template <int CURVE> const uint64_t* HIP_B::G1_words(const G1* a) { return a->data; }
+template <int CURVE> const uint64_t* HIP_B::G2_words(const G2* a) { return a->data; }
+
+template class mnt753_hip_impl<0>;
+template class mnt753_hip_impl<1>;

@@ -1,0 +1,82 @@
+"""CPU: the oracle (oracle/mnt753_oracle.c) against vectors minted by the REFERENCE's own code
+(oracle/mint_golden.cpp, tools/mint_e2e.sh).  This is what pins the oracle."""
+import filecmp
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import golden_io as G
+import oracle_lib as O
+
+
+@pytest.mark.parametrize("tag,mod", [("A", 0), ("B", 1)])
+def test_field_ops(tag, mod):
+    for a, b, ab, s, d, inv, neg, big in G.field(tag):
+        assert np.array_equal(O.field_op(mod, 0, a, b), ab)
+        assert np.array_equal(O.field_op(mod, 1, a, b), s)
+        assert np.array_equal(O.field_op(mod, 2, a, b), d)
+        assert np.array_equal(O.field_op(mod, 3, a), inv)
+        assert np.array_equal(O.field_op(mod, 5, a), neg)
+        assert np.array_equal(O.field_op(mod, 4, a), big)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("group", [1, 2])
+def test_group_ops(curve, group):
+    for r in G.group(curve, group):
+        assert np.array_equal(O.point_op(curve, group, 0, r["P"], r["Q"]), r["sum"])
+        assert np.array_equal(O.point_op(curve, group, 1, r["P"]), r["dbl"])
+        assert np.array_equal(O.point_op(curve, group, 2, r["P"], r["Q"]), r["diff"])
+        assert np.array_equal(O.point_op(curve, group, 3, r["P"], r["s"]), r["mul"])
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("group,n", [(1, n) for n in G.MSM_SIZES[1]] + [(2, n) for n in G.MSM_SIZES[2]])
+def test_msm(curve, group, n):
+    bases, scalars, result = G.msm(curve, group, n)
+    for chunks in (1, 4):   # the reference result does not depend on the OpenMP chunking
+        assert np.array_equal(O.msm(curve, group, bases, scalars, chunks), result)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("logm", G.FFT_LOGM)
+def test_fft(curve, logm):
+    v, outs = G.fft(curve, logm)
+    for kind in range(4):
+        assert np.array_equal(O.fft(curve, kind, v).reshape(-1, 12), outs[kind]), f"kind {kind}"
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("logm", G.H_LOGM)
+def test_compute_h(curve, logm):
+    ca, cb, cc, h = G.h(curve, logm)
+    assert np.array_equal(O.compute_h(curve, ca, cb, cc).reshape(-1, 12), h)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_end_to_end_proof(curve, tmp_path):
+    params, inp, expected = G.e2e_paths(curve)
+    out = str(tmp_path / "proof.bin")
+    O.prove(curve, params, inp, out, chunks=2)
+    assert filecmp.cmp(out, expected, shallow=False)
+
+
+def test_golden_manifest():
+    sums = os.path.join(G.GOLDEN, "SHA256SUMS")
+    for line in open(sums):
+        digest, name = line.split()
+        assert hashlib.sha256(open(os.path.join(G.GOLDEN, name), "rb").read()).hexdigest() == digest, name
+
+
+def test_reference_build_agrees_when_present(tmp_path):
+    """Where oracle/_ref exists (built from /root/reference), the reference binary itself re-proves the e2e set."""
+    ref_main = os.path.join(O.ROOT, "oracle", "_ref", "main")
+    if not os.path.exists(ref_main):
+        pytest.skip("oracle/_ref not built on this machine")
+    import subprocess
+    params, inp, expected = G.e2e_paths(1)
+    out = str(tmp_path / "ref.bin")
+    subprocess.check_call([ref_main, "MNT6753", "compute", params, inp, out], stdout=subprocess.DEVNULL)
+    assert filecmp.cmp(out, expected, shallow=False)
