@@ -10,3 +10,5 @@ from .api import (  # noqa: F401
     point_add, point_scale, point_to_affine, point_from_affine, vec_muleq, vec_subeq,
     synth_points, synth_scalars, synth_expected_msm, msm_last_timing, DeviceBuffer,
 )
+from . import parallel  # noqa: F401,E402
+from . import api  # noqa: F401,E402

@@ -263,3 +263,11 @@ def synth_expected_msm(curve, group, seed, scalars):
     out = np.zeros(projective_words(curve, group), dtype=np.uint64)
     _check(lib().mnt753_synth_expected_msm(curve, group, seed, s.size // 12, ps, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_synth_expected_msm")
     return out
+
+
+def mont_one(curve):
+    """Fr element 1 in wire (Montgomery) form: R mod r."""
+    r = [0x0001c4c62d92c41110229022eee2cdadb7f997505b8fafed5eb7e8f96c97d87307fdb925e8a0ed8d99d124d9a15af79db26c5c28c859a99b3eebca9429212636b9dff97634993aa4d6c381bc3f0057974ea099170fa13a4fd90776e240000001,
+         0x0001c4c62d92c41110229022eee2cdadb7f997505b8fafed5eb7e8f96c97d87307fdb925e8a0ed8d99d124d9a15af79db117e776f218059db80f0da5cb537e38685acce9767254a4638810719ac425f0e39d54522cdd119f5e9063de245e8001][curve]
+    v = (1 << 768) % r
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(12)], dtype=np.uint64)

@@ -1,0 +1,108 @@
+"""CPU: the C-ABI library loads, exports everything include/mnt753_hip.h declares, refuses to compute without a
+GPU (no silent fallback), and its host-side group helpers / synthetic generators agree with the goldens and oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_io as G
+import oracle_lib as O
+
+ROOT = O.ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mnt753_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mnt753_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = ctypes.CDLL(pkg.lib_path())
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mnt753_hip.h but not exported"
+    pkg.lib()   # the ctypes signature table resolves as well
+
+
+def test_sizes(pkg):
+    assert [pkg.affine_words(c, g) for c in (0, 1) for g in (1, 2)] == [24, 48, 24, 72]
+    assert [pkg.projective_words(c, g) for c in (0, 1) for g in (1, 2)] == [36, 72, 36, 108]
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_no_cpu_fallback(pkg):
+    L = pkg.lib()
+    assert L.mnt753_init(0) == -2                      # MNT753_ENODEV
+    assert b"no HIP device" in L.mnt753_last_error()
+    h = ctypes.c_void_p()
+    aff = np.zeros(24, dtype=np.uint64)
+    assert L.mnt753_bases_create(0, 1, ctypes.c_void_p(aff.ctypes.data), 0, 1, ctypes.byref(h)) == -2
+    assert L.mnt753_domain_create(0, 8, ctypes.byref(h)) == -2
+    assert L.mnt753_vec_muleq(0, ctypes.c_void_p(8), ctypes.c_void_p(8), 1, None) == -2
+    with pytest.raises(pkg.Mnt753Error):
+        pkg.init(0)
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    exe = os.path.join(ROOT, "snark-challenge-prover-reference_amd", "main_hip")
+    params, inp, _ = G.e2e_paths(0)
+    r = subprocess.run([exe, "MNT4753", "compute", params, inp, str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+    assert not (tmp_path / "o.bin").exists()
+
+
+def test_bad_arguments(pkg):
+    L = pkg.lib()
+    out = np.zeros(36, dtype=np.uint64)
+    p = out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    assert L.mnt753_point_add(7, 1, p, p, p) == -1
+    assert L.mnt753_point_add(0, 3, p, p, p) == -1
+    assert pkg.affine_words(5, 1) == 0
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("group", [1, 2])
+def test_host_group_ops_vs_reference_goldens(pkg, curve, group):
+    """mnt753_point_{from_affine,add,scale,to_affine} (host code of the product) on the reference's vectors."""
+    for r in G.group(curve, group):
+        P = pkg.point_from_affine(curve, group, r["P"])
+        Q = pkg.point_from_affine(curve, group, r["Q"])
+        assert np.array_equal(pkg.point_to_affine(curve, group, pkg.point_add(curve, group, P, Q)), r["sum"])
+        assert np.array_equal(pkg.point_to_affine(curve, group, pkg.point_add(curve, group, P, P)), r["dbl"])
+        assert np.array_equal(pkg.point_to_affine(curve, group, pkg.point_scale(curve, group, r["s"], P)), r["mul"])
+        assert np.array_equal(pkg.point_to_affine(curve, group, P), r["P"])
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("group", [1, 2])
+def test_synthetic_inputs(pkg, curve, group):
+    """deterministic, thread-count independent, and consistent with their discrete logs (checked by the oracle)."""
+    n = 1500 if group == 1 else 1100    # crosses the 1024-point chunk boundary
+    a = pkg.synth_points(curve, group, 99, n, threads=1)
+    b = pkg.synth_points(curve, group, 99, n, threads=5)
+    assert np.array_equal(a, b)
+    assert len({bytes(r) for r in a}) == n
+    sc = pkg.synth_scalars(curve, 7, n)
+    assert np.array_equal(sc, pkg.synth_scalars(curve, 7, n))
+    k = 40
+    exp = pkg.point_to_affine(curve, group, pkg.synth_expected_msm(curve, group, 99, sc[:k]))
+    assert np.array_equal(O.msm(curve, group, a[:k], sc[:k]), exp)
+    # across the chunk boundary
+    sel = slice(1010, 1040)
+    z = np.zeros_like(sc[:1040]); z[sel] = sc[sel]
+    exp = pkg.point_to_affine(curve, group, pkg.synth_expected_msm(curve, group, 99, z))
+    assert np.array_equal(O.msm(curve, group, a[sel], sc[sel]), exp)

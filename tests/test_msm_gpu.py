@@ -1,0 +1,116 @@
+"""GPU: MSM parity -- HIP path (through the C ABI) vs the reference's golden vectors, vs the CPU oracle on seeded
+inputs, and at full size through the known discrete logs of the synthetic bases.  Bit-exact (integer work)."""
+import numpy as np
+import pytest
+
+import golden_io as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+GROUPS = [(0, 1), (0, 2), (1, 1), (1, 2)]
+
+
+def gpu_msm_affine(pkg, curve, group, bases, scalars, **kw):
+    bs = pkg.BaseSet(curve, group, bases)
+    try:
+        return pkg.point_to_affine(curve, group, bs.msm(scalars, **kw))
+    finally:
+        bs.close()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("group,n", [(1, n) for n in G.MSM_SIZES[1]] + [(2, n) for n in G.MSM_SIZES[2]])
+def test_golden(gpu, curve, group, n):
+    bases, scalars, result = G.msm(curve, group, n)
+    assert np.array_equal(gpu_msm_affine(gpu, curve, group, bases, scalars), result)
+
+
+@pytest.mark.parametrize("curve,group", GROUPS)
+@pytest.mark.parametrize("n", [5, 64, 700])
+def test_vs_oracle_seeded(gpu, curve, group, n):
+    if group == 2 and n > 200:
+        n = 200
+    pts = gpu.synth_points(curve, group, 1000 + n, n)
+    sc = gpu.synth_scalars(curve, 2000 + n, n)
+    assert np.array_equal(gpu_msm_affine(gpu, curve, group, pts, sc), O.msm(curve, group, pts, sc, chunks=3))
+
+
+@pytest.mark.parametrize("curve,group", GROUPS)
+def test_edge_cases(gpu, curve, group):
+    n = 96
+    pts = gpu.synth_points(curve, group, 31, n)
+    sc = gpu.synth_scalars(curve, 32, n)
+    zero_aff = np.zeros(gpu.affine_words(curve, group), dtype=np.uint64)
+    bs = gpu.BaseSet(curve, group, pts)
+    # empty input -> identity
+    assert np.array_equal(gpu.point_to_affine(curve, group, bs.msm(sc[:0])), zero_aff)
+    # all-zero scalars -> identity
+    assert np.array_equal(gpu.point_to_affine(curve, group, bs.msm(np.zeros_like(sc))), zero_aff)
+    # every scalar equal (one giant bucket per window) and all ones
+    same = np.tile(sc[0], (n, 1))
+    assert np.array_equal(gpu.point_to_affine(curve, group, bs.msm(same)), O.msm(curve, group, pts, same))
+    ones = np.tile(gpu.api.mont_one(curve), (n, 1))
+    assert np.array_equal(gpu.point_to_affine(curve, group, bs.msm(ones)), O.msm(curve, group, pts, ones))
+    # base_offset / ragged length (vector_Fr_offset + shorter length, cuda_prover_piecewise.cu:79-81)
+    assert np.array_equal(gpu.point_to_affine(curve, group, bs.msm(sc[2:50], base_offset=7)), O.msm(curve, group, pts[7:55], sc[2:50]))
+    bs.close()
+    # identity bases everywhere, duplicates and opposite points
+    p2 = pts.copy(); p2[0] = 0; p2[n - 1] = 0; p2[10] = p2[11]; sc2 = sc.copy(); sc2[10] = sc2[11]
+    assert np.array_equal(gpu_msm_affine(gpu, curve, group, p2, sc2), O.msm(curve, group, p2, sc2))
+    allinf = np.zeros_like(pts)
+    assert np.array_equal(gpu_msm_affine(gpu, curve, group, allinf, sc), zero_aff)
+
+
+@pytest.mark.parametrize("c", [3, 7, 11, 16])
+def test_window_size_does_not_change_the_result(gpu, c):
+    n = 300
+    pts = gpu.synth_points(0, 1, 41, n); sc = gpu.synth_scalars(0, 42, n)
+    expect = O.msm(0, 1, pts, sc)
+    old = gpu.lib().mnt753_msm_set_window_bits(c)
+    try:
+        assert np.array_equal(gpu_msm_affine(gpu, 0, 1, pts, sc), expect)
+    finally:
+        gpu.lib().mnt753_msm_set_window_bits(old)
+
+
+def test_scalars_on_device_and_reuse(gpu):
+    n = 2048
+    pts = gpu.synth_points(1, 1, 51, n); sc = gpu.synth_scalars(1, 52, n)
+    bs = gpu.BaseSet(1, 1, pts)
+    d = gpu.DeviceBuffer.from_numpy(sc)
+    a = bs.msm(d.ptr.value, n=n, on_device=True)
+    b = bs.msm(sc)
+    assert np.array_equal(gpu.point_to_affine(1, 1, a), gpu.point_to_affine(1, 1, b))
+    exp = gpu.point_to_affine(1, 1, gpu.synth_expected_msm(1, 1, 51, sc))
+    assert np.array_equal(gpu.point_to_affine(1, 1, a), exp)
+    bs.close()
+
+
+def test_full_size_2pow20_g1_mnt4753(gpu):
+    """BASELINE config[1]: 2^20 G1 bases.  Exact check through the discrete logs of the synthetic bases
+    (sum_k s_k e_k mod r) * G, plus additivity MSM(s) + MSM(t) == MSM(s + t) as a size-independent property."""
+    n = 1 << 20
+    pts = gpu.synth_points(0, 1, 42, n)
+    s = gpu.synth_scalars(0, 43, n)
+    t = gpu.synth_scalars(0, 44, n)
+    bs = gpu.BaseSet(0, 1, pts)
+    ms = bs.msm(s)
+    assert np.array_equal(gpu.point_to_affine(0, 1, ms), gpu.point_to_affine(0, 1, gpu.synth_expected_msm(0, 1, 42, s)))
+    mt = bs.msm(t)
+    ds, dt = gpu.DeviceBuffer.from_numpy(s), gpu.DeviceBuffer.from_numpy(t)
+    # s + t in Fr through the library's own subeq: s - (0 - t)
+    z = gpu.DeviceBuffer.from_numpy(np.zeros_like(t))
+    gpu.vec_subeq(0, z.ptr.value, dt.ptr.value, n)       # z = -t
+    gpu.vec_subeq(0, ds.ptr.value, z.ptr.value, n)       # ds = s + t
+    mst = bs.msm(ds.ptr.value, n=n, on_device=True)
+    lhs = gpu.point_to_affine(0, 1, gpu.point_add(0, 1, ms, mt))
+    assert np.array_equal(lhs, gpu.point_to_affine(0, 1, mst))
+    bs.close()
+
+
+def test_large_g2_both_curves(gpu):
+    for curve, n in ((0, 1 << 14), (1, 1 << 13)):
+        pts = gpu.synth_points(curve, 2, 61, n); sc = gpu.synth_scalars(curve, 62, n)
+        got = gpu_msm_affine(gpu, curve, 2, pts, sc)
+        assert np.array_equal(got, gpu.point_to_affine(curve, 2, gpu.synth_expected_msm(curve, 2, 61, sc)))

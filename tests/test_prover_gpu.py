@@ -1,0 +1,46 @@
+"""GPU: the whole prover (C++ host mirror of B:: + CLI main_hip) against the reference's own proof files, and
+against the oracle on synthetic parameter sets.  The proof file must be byte-identical (README.md:55-58 of the
+reference defines parity as sha256 equality of the outputs)."""
+import filecmp
+import os
+import subprocess
+
+import pytest
+
+import golden_io as G
+import oracle_lib as O
+import synth_files
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(O.ROOT, "snark-challenge-prover-reference_amd", "main_hip")
+NAME = {0: "MNT4753", 1: "MNT6753"}
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("flags", [[], ["--fused-h"]])
+def test_reference_proof_files(gpu, curve, flags, tmp_path):
+    params, inp, expected = G.e2e_paths(curve)
+    out = str(tmp_path / "proof.bin")
+    r = subprocess.run([EXE, NAME[curve], "compute", params, inp, out] + flags, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Total time from input to output" in r.stdout
+    assert filecmp.cmp(out, expected, shallow=False)
+
+
+@pytest.mark.parametrize("curve,log2_d", [(0, 11), (1, 10)])
+def test_synthetic_set_vs_oracle(gpu, curve, log2_d, tmp_path):
+    """MNT6753 at 2^10 is the reference's `generate_parameters fast` size."""
+    params, inp = str(tmp_path / "params"), str(tmp_path / "input")
+    synth_files.write_files(gpu, curve, log2_d, params, inp)
+    out_gpu, out_cpu = str(tmp_path / "gpu.bin"), str(tmp_path / "cpu.bin")
+    r = subprocess.run([EXE, NAME[curve], "compute", params, inp, out_gpu, "--fused-h"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    O.prove(curve, params, inp, out_cpu)
+    assert filecmp.cmp(out_gpu, out_cpu, shallow=False)
+
+
+def test_cli_errors(gpu, tmp_path):
+    r = subprocess.run([EXE, "MNT4753", "compute", "/nonexistent", "/nonexistent", str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+    r = subprocess.run([EXE, "BN128", "compute", "a", "b", "c"], capture_output=True, text=True)
+    assert r.returncode == 2
