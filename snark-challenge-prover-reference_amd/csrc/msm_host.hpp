@@ -36,12 +36,26 @@ int pick_window_bits(size_t n) {
   return best;
 }
 
-MsmPlan make_plan(size_t n) {
+// window size when all windows share one bucket set: N*W bucket adds + one reduction of 2^(c-1) buckets
+int pick_precomp_bits(size_t n) {
+  if (const char* e = getenv("MNT753_MSM_PRE_C")) { int v = atoi(e); if (v >= 2 && v <= 24) return v; }
+  int best = 2; double best_cost = 1e300;
+  for (int c = 2; c <= 22; ++c) {
+    double W = (754 + c - 1) / c;
+    double cost = W * (double)n + 4.0 * (double)(1u << (c - 1)) * 14.0 / 11.0;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+MsmPlan make_plan(size_t n, int pre_c) {
   MsmPlan p;
-  p.c = pick_window_bits(n);
+  p.pre = pre_c > 0 && g_window_bits_override == 0;
+  p.c = p.pre ? pre_c : pick_window_bits(n);
   p.W = (754 + p.c - 1) / p.c;
   p.nb = 1u << (p.c - 1);
-  p.n_buckets = (uint32_t)p.W * p.nb;
+  p.n_sets = p.pre ? 1u : (uint32_t)p.W;
+  p.n_buckets = p.n_sets * p.nb;
   // lanes: aim at `rounds` full rounds of the machine (256 CUs x 256 lanes, one wave per SIMD)
   const uint64_t entries = (uint64_t)p.W * n;
   int rounds = 2;
@@ -83,7 +97,7 @@ void free_ws(mnt753_bases* b) {
 
 template <class C>
 int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
-  if (b->ws_n >= n && b->ws_plan.c == p.c && b->ws_plan.T == p.T && b->ws_plan.L == p.L && b->ws_plan.n_lanes >= p.n_lanes) return 0;
+  if (b->ws_n >= n && b->ws_plan.c == p.c && b->ws_plan.pre == p.pre && b->ws_plan.T == p.T && b->ws_plan.L == p.L && b->ws_plan.n_lanes >= p.n_lanes) return 0;
   free_ws(b);
   const size_t PW = proj_words<C>();
   const size_t nscan_blocks = ((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -100,7 +114,7 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_edge_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_flags, sizeof(uint32_t) * 40));
   HIP_TRY(hipMalloc(&b->d_part_a, sizeof(uint32_t) * PW * (size_t)p.n_chunks));
-  HIP_TRY(hipMalloc(&b->d_part_b, sizeof(uint32_t) * PW * ((size_t)p.n_chunks / 2 + (size_t)p.W)));
+  HIP_TRY(hipMalloc(&b->d_part_b, sizeof(uint32_t) * PW * ((size_t)p.n_chunks / 2 + (size_t)p.W + 4)));
   HIP_TRY(hipMalloc(&b->d_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_chunks));
   HIP_TRY(hipMalloc(&b->d_wire_out, sizeof(uint32_t) * 3 * wire_coord_words<C>() * (size_t)p.W));
   HIP_TRY(hipHostMalloc(&b->h_wire_out, sizeof(uint32_t) * 3 * wire_coord_words<C>() * (size_t)p.W));
@@ -113,7 +127,16 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
 template <class C>
 int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_t n) {
   const size_t wire_bytes = n * 2 * wire_coord_words<C>() * 4;
-  HIP_TRY(hipMalloc(&b->d_aff, sizeof(uint32_t) * aff_words<C>() * std::max<size_t>(n, 1)));
+  // window table: on by default for base sets large enough to amortise it (MNT753_MSM_PRECOMP=0 turns it off)
+  bool want_table = n >= 4096;
+  if (const char* e = getenv("MNT753_MSM_PRECOMP")) want_table = atoi(e) != 0 && n > 0;
+  int pc = 0, pW = 1;
+  if (want_table) {
+    pc = pick_precomp_bits(n);
+    pW = (754 + pc - 1) / pc;
+    if ((uint64_t)pW * n >= 0x7fffffffull) { want_table = false; pc = 0; pW = 1; }   // row index must fit 31 bits
+  }
+  HIP_TRY(hipMalloc(&b->d_aff, sizeof(uint32_t) * aff_words<C>() * std::max<size_t>(n, 1) * (size_t)pW));
   HIP_TRY(hipMalloc(&b->d_inf, std::max<size_t>(n, 1)));
   if (n == 0) return 0;
   const uint32_t* src = reinterpret_cast<const uint32_t*>(affine);
@@ -127,6 +150,24 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   if (staged) HIP_TRY(hipFree(staged));
+  if (want_table) {
+    const size_t tile = std::min<size_t>(n, (size_t)1 << 17);
+    const size_t EW = (size_t)C::F::DEG * FPS_WORDS;
+    uint32_t *ztmp = nullptr, *ptmp = nullptr;
+    HIP_TRY(hipMalloc(&ztmp, sizeof(uint32_t) * EW * tile * (size_t)pW));
+    HIP_TRY(hipMalloc(&ptmp, sizeof(uint32_t) * EW * tile * (size_t)pW));
+    for (size_t i0 = 0; i0 < n; i0 += tile) {
+      const size_t cnt = std::min(tile, n - i0);
+      hipLaunchKernelGGL((k_precompute_windows<C>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, b->d_aff, b->d_inf, ztmp, ptmp, n,
+                         i0, cnt, pc, pW);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(ztmp));
+    HIP_TRY(hipFree(ptmp));
+    b->pre_c = pc;
+    b->pre_W = pW;
+  }
   return 0;
 }
 
@@ -151,7 +192,7 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
     host::HPoint<HC>::zero().to_wire(out);
     return 0;
   }
-  MsmPlan p = make_plan(n);
+  MsmPlan p = make_plan(n, b->pre_c);
   if (int rc = ensure_ws<C>(b, n, p)) return rc;
   for (int i = 0; i < 5; ++i)
     if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
@@ -162,20 +203,22 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
     HIP_TRY(hipMemcpyAsync(b->d_scalars_stage, scalars, 96 * n, hipMemcpyHostToDevice, st));
     d_scal = reinterpret_cast<const uint32_t*>(b->d_scalars_stage);
   }
-  const uint32_t* d_aff = b->d_aff + base_offset * aff_words<C>();
+  // with the window table the sorted entries carry absolute table rows (w * n_total + base_offset + i)
+  const uint32_t* d_aff = p.pre ? b->d_aff : b->d_aff + base_offset * aff_words<C>();
   const uint8_t* d_inf = b->d_inf + base_offset;
   const size_t PW = proj_words<C>();
 
   HIP_TRY(hipEventRecord(b->ev[0], st));
   HIP_TRY(hipMemsetAsync(b->d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
   const unsigned gb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_hist, n, p.c, p.W);
+  hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_hist, n, p.c, p.W, p.pre ? 0u : p.nb);
   const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
   hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_hist, b->d_offsets, b->d_blocksums, (size_t)p.n_buckets);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
   hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total,
                      (size_t)p.n_buckets);
-  hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_cursor, b->d_sorted, n, p.c, p.W);
+  hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_cursor, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
+                     p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u);
   HIP_TRY(hipEventRecord(b->ev[1], st));
   hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
                      p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
@@ -196,23 +239,24 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
   hipLaunchKernelGGL((k_bucket_reduce<C>), dim3((p.n_chunks + 255) / 256), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,
                      b->d_tmp, p.nb, p.L, p.n_chunks, p.c - 1);
   // tree: [W][n_in] -> [W][1]
+  const uint32_t NS = p.n_sets;   // bucket sets = points that survive the reduction
   uint32_t n_in = p.nb / p.L;
   uint32_t* cur = b->d_part_a;
   uint32_t* nxt = b->d_part_b;
   const uint32_t R = 4;
   while (n_in > 1) {
     uint32_t n_out = (n_in + R - 1) / R;
-    hipLaunchKernelGGL((k_tree_sum<C>), dim3(((uint32_t)p.W * n_out + 255) / 256), dim3(256), 0, st, cur, nxt, (uint32_t)p.W, n_in, n_out, R);
+    hipLaunchKernelGGL((k_tree_sum<C>), dim3((NS * n_out + 255) / 256), dim3(256), 0, st, cur, nxt, NS, n_in, n_out, R);
     std::swap(cur, nxt);
     n_in = n_out;
   }
-  hipLaunchKernelGGL((k_points_to_wire<C>), dim3((p.W + 63) / 64), dim3(64), 0, st, cur, b->d_wire_out, (uint32_t)p.W);
+  hipLaunchKernelGGL((k_points_to_wire<C>), dim3((NS + 63) / 64), dim3(64), 0, st, cur, b->d_wire_out, NS);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[3], st));
-  HIP_TRY(hipMemcpyAsync(b->h_wire_out, b->d_wire_out, sizeof(uint64_t) * PWW * (size_t)p.W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_wire_out, b->d_wire_out, sizeof(uint64_t) * PWW * (size_t)NS, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   auto t0 = std::chrono::steady_clock::now();
-  horner_host<HC>(b->h_wire_out, p.W, p.c, out);
+  horner_host<HC>(b->h_wire_out, (int)NS, p.c, out);   // one point with the window table: a copy
   auto t1 = std::chrono::steady_clock::now();
   float ms;
   HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1])); g_last_timing[1] = ms;

@@ -169,7 +169,7 @@ __device__ __forceinline__ uint32_t lds_bits(const uint32_t* sw, int stride, int
 template <int FRM>
 __global__ void __launch_bounds__(256) k_scalar_digits(const uint32_t* __restrict__ scal_wire, const uint8_t* __restrict__ inf,
                                                       int32_t* __restrict__ digits, uint32_t* __restrict__ hist, size_t n,
-                                                      int c, int W) {
+                                                      int c, int W, uint32_t hist_stride) {
   __shared__ uint32_t sw[24 * 256];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int tid = threadIdx.x;
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint32_t* __restric
       digits[(size_t)w * n + i] = d;
     }
     uint32_t b = d ? (uint32_t)(d < 0 ? -d : d) - 1u : 0u;
-    wave_atomic_inc(hist + (size_t)w * nb, b, d != 0);
+    wave_atomic_inc(hist + (size_t)w * hist_stride, b, d != 0);
   }
 }
 
@@ -290,16 +290,18 @@ static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_finish(uint32_t* _
 }
 
 // ---- scatter: counting sort of (point, sign) by flattened bucket id ----------------------------
+// hist_stride = 2^(c-1) (one bucket set per window) or 0 (all windows share one bucket set: precomputed tables);
+// the sorted entry is the row index  w * entry_stride + entry_base + i  of the base table, plus the sign bit.
 static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
-                                                uint32_t* __restrict__ sorted, size_t n, int c, int W) {
+                                                uint32_t* __restrict__ sorted, size_t n, int c, int W, uint32_t hist_stride,
+                                                uint32_t entry_stride, uint32_t entry_base) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
-  const uint32_t nb = 1u << (c - 1);
   for (int w = 0; w < W; ++w) {
     int32_t d = live ? digits[(size_t)w * n + i] : 0;
     uint32_t b = d ? (uint32_t)(d < 0 ? -d : d) - 1u : 0u;
-    uint32_t pos = wave_atomic_inc(cursor + (size_t)w * nb, b, d != 0);
-    if (d != 0) sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    uint32_t pos = wave_atomic_inc(cursor + (size_t)w * hist_stride, b, d != 0);
+    if (d != 0) sorted[pos] = ((uint32_t)w * entry_stride + entry_base + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
   }
 }
 
@@ -545,6 +547,114 @@ __global__ void __launch_bounds__(64) k_points_to_wire(const uint32_t* __restric
     uint32_t w[24];
     fp_to_wire(w, F::comp(coord, k % F::DEG));
     store_wire24(dst + 24 * k, w);
+  }
+}
+
+
+// ---- precomputed window multiples ------------------------------------------------------------------
+// table[w][i] = 2^(c*w) * P_i in affine device form, w < W.  With it every window's digit of a scalar indexes the
+// SAME bucket set (sum_w d_w * (2^(cw) P) = s * P), so one MSM needs W*N bucket additions into 2^(c-1) buckets,
+// ONE bucket reduction instead of W, and no Horner pass.  Built once per base set, at parameter-load time
+// (the reference's timing window opens after the parameters are loaded, libsnark/main.cpp:201-203).
+template <int M>
+__device__ void fp_inv_fermat(Fp<M>& r, const Fp<M>& x) {
+  // x^(p-2), exponent limbs from the constants table
+  Fp<M> acc, a, b, t;
+  fp_one(acc);
+  bool started = false;
+#pragma unroll 1
+  for (int i = NL * LB - 1; i >= 0; --i) {
+    const uint32_t limb = FPC[M].pm2[i / LB];
+    const bool bit = (limb >> (i % LB)) & 1u;
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+      if (phase == 0) { if (!started) continue; a = acc; b = acc; }
+      else { if (!bit) continue; a = acc; b = x; started = true; }
+      fp_mul(t, a, b);
+      acc = t;
+    }
+  }
+  r = acc;
+}
+template <int M>
+__device__ void e_inv(Fp<M>& r, const Fp<M>& a, FieldFp<M>*) { fp_inv_fermat(r, a); }
+template <int M, unsigned NR>
+__device__ void e_inv(Fp2E<M>& r, const Fp2E<M>& x, FieldFp2<M, NR>*) {   // fp2.tcc:129-142
+  Fp<M> t0, t1, t2, t3;
+  fp_mul(t0, x.c0, x.c0);
+  fp_mul(t1, x.c1, x.c1);
+  fp_mul_small(t1, t1, NR);
+  fp_sub(t2, t0, t1);
+  fp_inv_fermat(t3, t2);
+  fp_mul(r.c0, x.c0, t3);
+  fp_mul(t0, x.c1, t3);
+  fp_neg(r.c1, t0);
+}
+template <int M, unsigned NR>
+__device__ void e_inv(Fp3E<M>& r, const Fp3E<M>& x, FieldFp3<M, NR>*) {   // fp3.tcc:126-143
+  Fp<M> t0, t1, t2, t3, t4, t5, c0, c1, c2, u, v, t6;
+  fp_mul(t0, x.c0, x.c0); fp_mul(t1, x.c1, x.c1); fp_mul(t2, x.c2, x.c2);
+  fp_mul(t3, x.c0, x.c1); fp_mul(t4, x.c0, x.c2); fp_mul(t5, x.c1, x.c2);
+  fp_mul_small(u, t5, NR); fp_sub(c0, t0, u);
+  fp_mul_small(u, t2, NR); fp_sub(c1, u, t3);
+  fp_sub(c2, t1, t4);
+  fp_mul(u, x.c2, c1); fp_mul(v, x.c1, c2); fp_add(u, u, v); fp_mul_small(u, u, NR);
+  fp_mul(v, x.c0, c0); fp_add(u, u, v);
+  fp_inv_fermat(t6, u);
+  fp_mul(r.c0, t6, c0); fp_mul(r.c1, t6, c1); fp_mul(r.c2, t6, c2);
+}
+
+// one lane per point of a tile [i0, i0 + count):  table rows for w >= 1; row 0 is the base itself (d_aff).
+//   ztmp: [W][count] E  (Z_w, then reused),  ptmp: [W][count] E (prefix products)
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_precompute_windows(uint32_t* __restrict__ table, const uint8_t* __restrict__ inf,
+                                                              uint32_t* __restrict__ ztmp, uint32_t* __restrict__ ptmp, size_t n_total,
+                                                              size_t i0, size_t count, int c, int W) {
+  using F = typename C::F;
+  using E = typename F::E;
+  constexpr int EW = F::DEG * FPS_WORDS;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const size_t i = i0 + t;
+  if (inf[i]) return;   // identity bases never enter a bucket (their digits are forced to 0)
+  Proj<C> R, Q;
+  e_load<F>(R.X, table + i * aff_words<C>());
+  e_load<F>(R.Y, table + i * aff_words<C>() + EW);
+  F::one(R.Z);
+  pt_set_zero(Q);
+  // pass 1: R_w = 2^c R_{w-1} (projective); keep X, Y in the table row and Z in ztmp
+#pragma unroll 1
+  for (int w = 1; w < W; ++w) {
+#pragma unroll 1
+    for (int k = 0; k < c; ++k) pt_vm<C, false>(R, Q, PC_DBL);
+    uint32_t* row = table + ((size_t)w * n_total + i) * aff_words<C>();
+    e_store<F>(row, R.X);
+    e_store<F>(row + EW, R.Y);
+    e_store<F>(ztmp + ((size_t)w * count + t) * EW, R.Z);
+  }
+  // pass 2: batch inversion of Z_1..Z_{W-1} (Montgomery's trick) and normalisation to affine
+  E pre, z, inv, zi, x, y, tmp;
+  F::one(pre);
+#pragma unroll 1
+  for (int w = 1; w < W; ++w) {
+    e_store<F>(ptmp + ((size_t)w * count + t) * EW, pre);       // product of Z_1..Z_{w-1}
+    e_load<F>(z, ztmp + ((size_t)w * count + t) * EW);
+    F::mul(tmp, pre, z);
+    pre = tmp;
+  }
+  e_inv(inv, pre, (F*)nullptr);
+#pragma unroll 1
+  for (int w = W - 1; w >= 1; --w) {
+    e_load<F>(tmp, ptmp + ((size_t)w * count + t) * EW);
+    e_load<F>(z, ztmp + ((size_t)w * count + t) * EW);
+    F::mul(zi, inv, tmp);                                      // 1 / Z_w
+    F::mul(tmp, inv, z);
+    inv = tmp;
+    uint32_t* row = table + ((size_t)w * n_total + i) * aff_words<C>();
+    e_load<F>(x, row);
+    e_load<F>(y, row + EW);
+    F::mul(tmp, x, zi); e_store<F>(row, tmp);
+    F::mul(tmp, y, zi); e_store<F>(row + EW, tmp);
   }
 }
 

@@ -12,14 +12,17 @@ struct MsmPlan {
   uint32_t T;         // sorted entries per accumulate lane
   uint32_t n_lanes;   // accumulate lanes
   uint32_t L;         // buckets per reduce lane
-  uint32_t n_chunks;  // W * nb / L
+  uint32_t n_chunks;  // n_sets * nb / L
+  int pre;            // 1: all windows share one bucket set (precomputed window multiples)
+  uint32_t n_sets;    // bucket sets: W, or 1 with the table
 };
 }  // namespace mnt753
 
 struct mnt753_bases {
   int curve, group;
   size_t n;
-  uint32_t* d_aff = nullptr;   // device affine, internal form
+  uint32_t* d_aff = nullptr;   // device affine, internal form: pre_W * n rows when the window table is built (row w*n + i = 2^(c w) P_i)
+  int pre_c = 0, pre_W = 0;    // window bits / windows of the precomputed table (0 = no table)
   uint8_t* d_inf = nullptr;    // identity flags
   // workspace (sized for an MSM over all n bases; reused by every call)
   size_t ws_n = 0;
