@@ -115,8 +115,8 @@ def main():
         value = world * n * args.steps / elapsed
         acc = float(np.mean(acc_ms))
         achieved = ALGO_BYTES_PER_PAIR * n / (acc * 1e-3) / 1e9
-        plan_c = int(os.environ.get("MNT753_MSM_C", "0")) or 16
-        windows = (754 + plan_c - 1) // plan_c
+        plan = pkg.msm_last_plan()
+        plan_c, windows = plan["window_bits"], plan["windows"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01", "accumulate_traffic.json")
         if os.path.exists(tpath) and args.log_n == LOG_N:
@@ -137,11 +137,12 @@ def main():
             "parity_ok": ok,
             "config": {"workload": f"MNT4753 G1 Pippenger MSM, 2^{args.log_n} bases per GPU, bit-exact vs libff::multi_exp",
                        "curve": "MNT4753", "group": "G1", "points_per_gpu": n, "window_bits": plan_c, "windows": windows,
+                       "window_table": plan["window_table"],
                        "parallelism": f"slice-per-gpu x{world}, all_gather of one projective point per rank"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "kernel": "k_bucket_accumulate<Mnt4G1>", "kernel_ms": acc,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PAIR * n,
-                         "note": "integer-ALU bound, not HBM bound: 11 Montgomery products per bucket addition",
+                         "note": "integer-ALU bound, not HBM bound: 11 Montgomery products per bucket addition, windows x 2^20 additions per launch",
                          "modmul_per_s": 11.0 * windows * n / (acc * 1e-3), "modmul_peak_per_s": MODMUL_PEAK_PER_S,
                          "modmul_frac": 11.0 * windows * n / (acc * 1e-3) / MODMUL_PEAK_PER_S},
             "phases_ms": {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},

@@ -91,6 +91,9 @@ int mnt753_msm_set_window_bits(int c);
 /* time of the last mnt753_msm call's kernels in milliseconds (HIP events on the launch stream):
  * index 0 = total, 1 = digits+sort, 2 = bucket accumulation kernel, 3 = bucket reduction, 4 = host tail */
 int mnt753_msm_last_timing(float out_ms[5]);
+/* plan of the last mnt753_msm call: [0] window bits c, [1] windows W, [2] 1 if the precomputed window table was used,
+ * [3] sorted entries per accumulate lane T */
+int mnt753_msm_last_plan(int out[4]);
 
 /* ---- small group operations on the host (O(1) work per proof) ------------------------------------ */
 /* replaces B::G1_add (hpp:32) */

@@ -47,6 +47,7 @@ def lib():
         "mnt753_msm": (i, [vp, sz, vp, i, sz, u64p, vp]),
         "mnt753_msm_set_window_bits": (i, [i]),
         "mnt753_msm_last_timing": (i, [C.POINTER(C.c_float)]),
+        "mnt753_msm_last_plan": (i, [C.POINTER(C.c_int)]),
         "mnt753_point_add": (i, [i, i, u64p, u64p, u64p]),
         "mnt753_point_scale": (i, [i, i, u64p, u64p, u64p]),
         "mnt753_point_to_affine": (i, [i, i, u64p, u64p]),
@@ -140,6 +141,12 @@ def msm_last_timing():
     t = (C.c_float * 5)()
     _check(lib().mnt753_msm_last_timing(t), "mnt753_msm_last_timing")
     return dict(total_ms=t[0], sort_ms=t[1], accumulate_ms=t[2], reduce_ms=t[3], host_ms=t[4])
+
+
+def msm_last_plan():
+    t = (C.c_int * 4)()
+    _check(lib().mnt753_msm_last_plan(t), "mnt753_msm_last_plan")
+    return dict(window_bits=t[0], windows=t[1], window_table=bool(t[2]), entries_per_lane=t[3])
 
 
 def point_add(curve, group, a, b):

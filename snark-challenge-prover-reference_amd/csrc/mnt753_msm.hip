@@ -9,6 +9,7 @@
 namespace mnt753 {
 int g_window_bits_override = 0;
 float g_last_timing[5] = {0, 0, 0, 0, 0};
+int g_last_plan[4] = {0, 0, 0, 0};
 }
 using namespace mnt753;
 
@@ -63,6 +64,12 @@ int mnt753_msm_set_window_bits(int c) {
 int mnt753_msm_last_timing(float out_ms[5]) {
   if (!out_ms) return set_error(MNT753_EINVAL, "msm_last_timing: null");
   memcpy(out_ms, g_last_timing, sizeof(g_last_timing));
+  return 0;
+}
+
+int mnt753_msm_last_plan(int out[4]) {
+  if (!out) return set_error(MNT753_EINVAL, "msm_last_plan: null");
+  memcpy(out, g_last_plan, sizeof(g_last_plan));
   return 0;
 }
 

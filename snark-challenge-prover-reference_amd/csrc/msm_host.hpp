@@ -19,6 +19,7 @@ using namespace mnt753;
 namespace mnt753 {
 extern int g_window_bits_override;
 extern float g_last_timing[5];
+extern int g_last_plan[4];
 }
 namespace {
 
@@ -194,6 +195,7 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
   }
   MsmPlan p = make_plan(n, b->pre_c);
   if (int rc = ensure_ws<C>(b, n, p)) return rc;
+  g_last_plan[0] = p.c; g_last_plan[1] = p.W; g_last_plan[2] = p.pre; g_last_plan[3] = (int)p.T;
   for (int i = 0; i < 5; ++i)
     if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
   const uint32_t* d_scal;

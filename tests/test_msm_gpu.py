@@ -74,6 +74,25 @@ def test_window_size_does_not_change_the_result(gpu, c):
         gpu.lib().mnt753_msm_set_window_bits(old)
 
 
+@pytest.mark.parametrize("curve,group", GROUPS)
+def test_window_table_mode_small(gpu, curve, group, monkeypatch):
+    """Force the precomputed-window-table path (default only for >= 4096 bases) on a set with every special case."""
+    monkeypatch.setenv("MNT753_MSM_PRECOMP", "1")
+    n = 150
+    pts = gpu.synth_points(curve, group, 71, n); sc = gpu.synth_scalars(curve, 72, n)
+    pts[0] = 0; pts[n - 1] = 0; pts[10] = pts[11]; sc[10] = sc[11]; sc[3] = 0; sc[4] = gpu.api.mont_one(curve)
+    bs = gpu.BaseSet(curve, group, pts)
+    got = gpu.point_to_affine(curve, group, bs.msm(sc))
+    assert gpu.msm_last_plan()["window_table"]
+    assert np.array_equal(got, O.msm(curve, group, pts, sc))
+    assert np.array_equal(gpu.point_to_affine(curve, group, bs.msm(sc[5:90], base_offset=20)), O.msm(curve, group, pts[20:105], sc[5:90]))
+    monkeypatch.setenv("MNT753_MSM_PRECOMP", "0")
+    bs2 = gpu.BaseSet(curve, group, pts)
+    assert np.array_equal(gpu.point_to_affine(curve, group, bs2.msm(sc)), got)
+    assert not gpu.msm_last_plan()["window_table"]
+    bs.close(); bs2.close()
+
+
 def test_scalars_on_device_and_reuse(gpu):
     n = 2048
     pts = gpu.synth_points(1, 1, 51, n); sc = gpu.synth_scalars(1, 52, n)
