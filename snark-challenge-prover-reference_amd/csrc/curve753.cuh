@@ -145,16 +145,19 @@ struct Mnt4G1 {  // y^2 = x^3 + 2x + b over Fq = B          (mnt4753_init.cpp:11
   using F = FieldFp<MOD_B>;
   static constexpr int FR = MOD_A;
   static HD void mul_by_a(F::E& r, const F::E& x) { fp_add(r, x, x); }
+  static HD void coeff_a(F::E& r) { F::E o; F::one(o); mul_by_a(r, o); }   // the curve coefficient a as a field element
 };
 struct Mnt6G1 {  // y^2 = x^3 + 11x + b over Fq = A         (mnt6753_init.cpp:130)
   using F = FieldFp<MOD_A>;
   static constexpr int FR = MOD_B;
   static HD void mul_by_a(F::E& r, const F::E& x) { fp_mul_small(r, x, 11u); }
+  static HD void coeff_a(F::E& r) { F::E o; F::one(o); mul_by_a(r, o); }
 };
 struct Mnt4G2 {  // twist over Fq2, a' = (2*13, 0): mul_by_a(c0,c1) = (26 c0, 26 c1)   (mnt4753_g2.cpp:31-34)
   using F = FieldFp2<MOD_B, 13u>;
   static constexpr int FR = MOD_A;
   static HD void mul_by_a(F::E& r, const F::E& x) { fp_mul_small(r.c0, x.c0, 26u); fp_mul_small(r.c1, x.c1, 26u); }
+  static HD void coeff_a(F::E& r) { F::E o; F::one(o); mul_by_a(r, o); }   // a' = (26, 0)
 };
 struct Mnt6G2 {  // twist over Fq3, a' = (0,0,11): mul_by_a(c0,c1,c2) = (121 c1, 121 c2, 11 c0)  (mnt6753_g2.cpp:38-41)
   using F = FieldFp3<MOD_A, 11u>;
@@ -166,6 +169,7 @@ struct Mnt6G2 {  // twist over Fq3, a' = (0,0,11): mul_by_a(c0,c1,c2) = (121 c1,
     fp_mul_small(t.c2, x.c0, 11u);
     r = t;
   }
+  static HD void coeff_a(F::E& r) { F::E o; F::one(o); mul_by_a(r, o); }   // a' = (0, 0, 11)
 };
 
 template <class C>
@@ -229,17 +233,13 @@ HD void pt_vm(Proj<C>& P, const Proj<C>& Q, int pc) {
       case 24: a = u; b = u; break;
       case 25: a = t3; b = v; break;
       case 26: F::sub(a, t4, t3); b = u; break;
-      default:
-        if (WITH_ADD) {
-          switch (pc) {
-            case 32: a = P.X; b = Q.Z; break;
-            case 33: a = P.Y; b = Q.Z; break;
-            case 34: a = Q.X; b = P.Z; break;
-            case 35: a = Q.Y; b = P.Z; break;
-            default: a = P.Z; b = Q.Z; break;  // 36
-          }
-        }
-        break;
+      // (flat on purpose: a switch nested in `default:` was miscompiled for a lane-divergent pc by hipcc 7.2)
+      case 32: if (WITH_ADD) { a = P.X; b = Q.Z; } break;
+      case 33: if (WITH_ADD) { a = P.Y; b = Q.Z; } break;
+      case 34: if (WITH_ADD) { a = Q.X; b = P.Z; } break;
+      case 35: if (WITH_ADD) { a = Q.Y; b = P.Z; } break;
+      case 36: if (WITH_ADD) { a = P.Z; b = Q.Z; } break;
+      default: break;
     }
     F::mul(r, a, b);
     switch (pc) {
@@ -277,23 +277,16 @@ HD void pt_vm(Proj<C>& P, const Proj<C>& Q, int pc) {
       case 24: F::sub(r, r, t4); F::sub(t3, r, t4); pc = 25; break;   // h = w^2 - 2B
       case 25: P.X = r; pc = 26; break;                          // X3 = h*s
       case 26: F::sub(r, r, t5); F::sub(P.Y, r, t5); pc = PC_END; break;  // Y3 = w*(B-h) - 2RR
-      default:
-        if (WITH_ADD) {
-          switch (pc) {
-            case 32: P.X = r; pc = 33; break;                    // X1Z2
-            case 33: P.Y = r; pc = 34; break;                    // Y1Z2
-            case 34: F::sub(v, r, P.X); pc = 35; break;          // v = X2Z1 - X1Z2
-            case 35:
-              F::sub(u, r, P.Y);                                 // u = Y2Z1 - Y1Z2
-              if (F::is_zero(u) && F::is_zero(v)) { P.X = Q.X; P.Y = Q.Y; P.Z = Q.Z; pc = PC_DBL; }
-              else pc = 36;
-              break;
-            default: P.Z = r; pc = 2; break;                     // Z1Z2, continue with shared tail
-          }
-        } else {
-          pc = PC_END;
-        }
+      case 32: P.X = r; pc = 33; break;                          // X1Z2
+      case 33: P.Y = r; pc = 34; break;                          // Y1Z2
+      case 34: F::sub(v, r, P.X); pc = 35; break;                // v = X2Z1 - X1Z2
+      case 35:
+        F::sub(u, r, P.Y);                                       // u = Y2Z1 - Y1Z2
+        if (F::is_zero(u) && F::is_zero(v)) { P.X = Q.X; P.Y = Q.Y; P.Z = Q.Z; pc = PC_DBL; }
+        else pc = 36;
         break;
+      case 36: P.Z = r; pc = 2; break;                           // Z1Z2, continue with the shared tail
+      default: pc = PC_END; break;
     }
   }
 }

@@ -86,11 +86,12 @@ int proj_w() { return proj_words<C>(); }
 
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
-                  b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage};
+                  b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage, b->d_raw_buckets, b->d_raw_edges, b->d_bucket_state};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
   b->d_digits = nullptr; b->d_hist = b->d_offsets = b->d_cursor = b->d_blocksums = b->d_total = nullptr;
   b->d_edge_tmp = b->d_edge_flags = nullptr;
+  b->d_raw_buckets = b->d_raw_edges = nullptr; b->d_bucket_state = nullptr;
   b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
   b->h_wire_out = nullptr; b->d_scalars_stage = nullptr;
   b->ws_n = 0;
@@ -112,6 +113,9 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_buckets, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_edges, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_bucket, sizeof(uint32_t) * 2 * (size_t)p.n_lanes));
+  HIP_TRY(hipMalloc(&b->d_raw_buckets, sizeof(uint32_t) * xyzz_words<C>() * (size_t)p.n_buckets));
+  HIP_TRY(hipMalloc(&b->d_raw_edges, sizeof(uint32_t) * xyzz_words<C>() * 2 * (size_t)p.n_lanes));
+  HIP_TRY(hipMalloc(&b->d_bucket_state, (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_edge_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_flags, sizeof(uint32_t) * 40));
   HIP_TRY(hipMalloc(&b->d_part_a, sizeof(uint32_t) * PW * (size_t)p.n_chunks));
@@ -222,8 +226,22 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
   hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_cursor, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
                      p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u);
   HIP_TRY(hipEventRecord(b->ev[1], st));
-  hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
-                     p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
+  // accumulate kernel: the lane-divergent projective VM (default: measured faster) or the wave-uniform XYZZ
+  // programs of vm_uniform.cuh (MNT753_MSM_ACC=uniform)
+  bool uniform_acc = false;
+  if (const char* e = getenv("MNT753_MSM_ACC")) uniform_acc = strcmp(e, "uniform") == 0;
+  if (uniform_acc) {
+    HIP_TRY(hipMemsetAsync(b->d_bucket_state, 0, (size_t)p.n_buckets, st));
+    hipLaunchKernelGGL((k_bucket_accumulate_u<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
+                       p.n_buckets, b->d_raw_buckets, b->d_raw_edges, b->d_edge_bucket, b->d_bucket_state, p.T, p.n_lanes);
+    hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, b->d_raw_buckets, b->d_buckets,
+                       b->d_bucket_state, (const uint32_t*)nullptr, p.n_buckets);
+    hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_raw_edges, b->d_edges,
+                       (const uint8_t*)nullptr, b->d_edge_bucket, 2 * p.n_lanes);
+  } else {
+    hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
+                       p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
+  }
   HIP_TRY(hipEventRecord(b->ev[2], st));
   {
     const uint32_t n_slots = 2 * p.n_lanes;
@@ -245,7 +263,7 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
   uint32_t n_in = p.nb / p.L;
   uint32_t* cur = b->d_part_a;
   uint32_t* nxt = b->d_part_b;
-  const uint32_t R = 4;
+  const uint32_t R = 2;   // log-depth: every level is one group addition deep
   while (n_in > 1) {
     uint32_t n_out = (n_in + R - 1) / R;
     hipLaunchKernelGGL((k_tree_sum<C>), dim3((NS * n_out + 255) / 256), dim3(256), 0, st, cur, nxt, NS, n_in, n_out, R);

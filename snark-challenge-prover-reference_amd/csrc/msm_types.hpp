@@ -32,6 +32,8 @@ struct mnt753_bases {
   uint32_t* d_sorted = nullptr;
   uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr, *d_edge_tmp = nullptr, *d_edge_flags = nullptr;
   uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;
+  uint32_t *d_raw_buckets = nullptr, *d_raw_edges = nullptr;   // XYZZ slots of the wave-uniform accumulate kernel
+  uint8_t* d_bucket_state = nullptr;
   uint32_t* d_wire_out = nullptr;
   uint64_t* h_wire_out = nullptr;   // pinned
   uint64_t* d_scalars_stage = nullptr;
