@@ -64,6 +64,8 @@ int mnt753_dev_alloc(void** dev_ptr, size_t bytes);
 int mnt753_dev_free(void* dev_ptr);
 int mnt753_copy_h2d(void* dev_dst, const void* src, size_t bytes);
 int mnt753_copy_d2h(void* dst, const void* dev_src, size_t bytes);
+int mnt753_copy_d2d(void* dev_dst, const void* dev_src, size_t bytes);
+int mnt753_dev_memset(void* dev_dst, int value, size_t bytes);
 int mnt753_sync(void* stream);
 
 /* ---- MSM --------------------------------------------------------------------------------------
@@ -83,8 +85,13 @@ size_t mnt753_bases_size(const mnt753_bases* b);
  * (NOT normalised to Z = 1; feed it to mnt753_point_to_affine / mnt753_point_add). */
 int mnt753_msm(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n,
                uint64_t* out_projective, void* stream);
-/* the same, split for multi-GPU use: per-device partial sums are exchanged by the caller (RCCL) and
- * folded with mnt753_point_add. Identical to mnt753_msm on one device. */
+/* The same, asynchronous: _start enqueues every kernel of the MSM and returns; _finish waits for it and writes the
+ * result.  stream == NULL uses a non-blocking stream owned by the base set, ordered after all work already enqueued on
+ * the default stream -- so the five MSMs of one proof (A, B1, B2, L, H: independent, cuda_prover_piecewise.cu:71-81) run
+ * concurrently and the latency-bound reduction tail of one overlaps the bucket accumulation of another.  At most one
+ * MSM may be in flight per base set. */
+int mnt753_msm_start(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n, void* stream);
+int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective);
 
 /* window size override (0 = automatic); returns previous value.  Tuning knob, not part of the reference. */
 int mnt753_msm_set_window_bits(int c);

@@ -40,11 +40,15 @@ def lib():
         "mnt753_dev_free": (i, [vp]),
         "mnt753_copy_h2d": (i, [vp, vp, sz]),
         "mnt753_copy_d2h": (i, [vp, vp, sz]),
+        "mnt753_copy_d2d": (i, [vp, vp, sz]),
+        "mnt753_dev_memset": (i, [vp, i, sz]),
         "mnt753_sync": (i, [vp]),
         "mnt753_bases_create": (i, [i, i, vp, i, sz, C.POINTER(vp)]),
         "mnt753_bases_free": (i, [vp]),
         "mnt753_bases_size": (sz, [vp]),
         "mnt753_msm": (i, [vp, sz, vp, i, sz, u64p, vp]),
+        "mnt753_msm_start": (i, [vp, sz, vp, i, sz, vp]),
+        "mnt753_msm_finish": (i, [vp, u64p]),
         "mnt753_msm_set_window_bits": (i, [i]),
         "mnt753_msm_last_timing": (i, [C.POINTER(C.c_float)]),
         "mnt753_msm_last_plan": (i, [C.POINTER(C.c_int)]),
@@ -123,6 +127,16 @@ class BaseSet:
         st = C.c_void_p(int(stream)) if stream else C.c_void_p()
         _check(lib().mnt753_msm(self._h, base_offset, sptr, 1 if on_device else 0, cnt,
                                 out.ctypes.data_as(C.POINTER(C.c_uint64)), st), "mnt753_msm")
+        return out
+
+    def msm_start(self, scalars_dev_ptr, n, base_offset=0, stream=None):
+        """Enqueue sum scalars[i] * bases[base_offset + i] (scalars resident on the device); collect with msm_finish()."""
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+        _check(lib().mnt753_msm_start(self._h, base_offset, C.c_void_p(int(scalars_dev_ptr)), 1, int(n), st), "mnt753_msm_start")
+
+    def msm_finish(self):
+        out = np.zeros(projective_words(self.curve, self.group), dtype=np.uint64)
+        _check(lib().mnt753_msm_finish(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_msm_finish")
         return out
 
     def close(self):

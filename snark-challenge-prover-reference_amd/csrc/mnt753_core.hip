@@ -131,6 +131,18 @@ int mnt753_copy_d2h(void* dst, const void* dev_src, size_t bytes) {
   HIP_TRY(hipMemcpy(dst, dev_src, bytes, hipMemcpyDeviceToHost));
   return 0;
 }
+int mnt753_copy_d2d(void* dev_dst, const void* dev_src, size_t bytes) {
+  if (int rc = require_device()) return rc;
+  if (bytes && (!dev_dst || !dev_src)) return set_error(MNT753_EINVAL, "copy_d2d: null");
+  HIP_TRY(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, nullptr));
+  return 0;
+}
+int mnt753_dev_memset(void* dev_dst, int value, size_t bytes) {
+  if (int rc = require_device()) return rc;
+  if (bytes && !dev_dst) return set_error(MNT753_EINVAL, "dev_memset: null");
+  HIP_TRY(hipMemsetAsync(dev_dst, value, bytes, nullptr));
+  return 0;
+}
 int mnt753_sync(void* stream) {
   if (int rc = require_device()) return rc;
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));

@@ -36,6 +36,8 @@ int mnt753_bases_free(mnt753_bases* b) {
   if (b->d_aff) (void)hipFree(b->d_aff);
   if (b->d_inf) (void)hipFree(b->d_inf);
   for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  if (b->ev_dep) (void)hipEventDestroy(b->ev_dep);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
   return 0;
 }
@@ -53,6 +55,40 @@ int mnt753_msm(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int
                                  : msm_mnt4g2(b, base_offset, scalars, scalars_on_device, n, out_projective, st);
   return b->group == MNT753_G1 ? msm_mnt6g1(b, base_offset, scalars, scalars_on_device, n, out_projective, st)
                                : msm_mnt6g2(b, base_offset, scalars, scalars_on_device, n, out_projective, st);
+}
+
+// asynchronous pair: start enqueues the whole MSM and returns; finish waits for it and writes the result
+int mnt753_msm_start(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n, void* stream) {
+  if (!b || (n && !scalars)) return set_error(MNT753_EINVAL, "msm_start: null argument");
+  if (base_offset + n > b->n) return set_error(MNT753_EINVAL, "msm_start: base_offset + n exceeds the base set");
+  if (int rc = require_device()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (!st) {
+    // the base set's own non-blocking stream, ordered after everything already enqueued on the default stream
+    if (!b->own_stream) HIP_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    if (!b->ev_dep) HIP_TRY(hipEventCreateWithFlags(&b->ev_dep, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->ev_dep, nullptr));
+    HIP_TRY(hipStreamWaitEvent(b->own_stream, b->ev_dep, 0));
+    st = b->own_stream;
+  }
+  const bool was_pending = b->pending != 0;
+  int rc;
+  if (b->curve == MNT753_CURVE_MNT4753)
+    rc = b->group == MNT753_G1 ? msm_start_mnt4g1(b, base_offset, scalars, scalars_on_device, n, st)
+                               : msm_start_mnt4g2(b, base_offset, scalars, scalars_on_device, n, st);
+  else
+    rc = b->group == MNT753_G1 ? msm_start_mnt6g1(b, base_offset, scalars, scalars_on_device, n, st)
+                               : msm_start_mnt6g2(b, base_offset, scalars, scalars_on_device, n, st);
+  if (rc && !was_pending) b->pending = 0;   // a failed start leaves nothing in flight
+  return rc;
+}
+
+int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective) {
+  if (!b || !out_projective) return set_error(MNT753_EINVAL, "msm_finish: null argument");
+  if (int rc = require_device()) return rc;
+  if (b->curve == MNT753_CURVE_MNT4753)
+    return b->group == MNT753_G1 ? msm_finish_mnt4g1(b, out_projective) : msm_finish_mnt4g2(b, out_projective);
+  return b->group == MNT753_G1 ? msm_finish_mnt6g1(b, out_projective) : msm_finish_mnt6g2(b, out_projective);
 }
 
 int mnt753_msm_set_window_bits(int c) {

@@ -189,14 +189,13 @@ void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
   acc.to_wire(out);
 }
 
+// Enqueue one MSM on stream `st` (no host synchronisation); msm_finish_t collects the result.
 template <class C, class HC>
-int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n, uint64_t* out,
-          hipStream_t st) {
+int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n, hipStream_t st) {
   const int PWW = 36 * HC::F::DEG;  // projective words (u64) on the wire
-  if (n == 0) {
-    host::HPoint<HC>::zero().to_wire(out);
-    return 0;
-  }
+  if (b->pending) return set_error(MNT753_EINVAL, "msm_start: this base set already has an MSM in flight (finish it first)");
+  b->pending = 1; b->pending_n = n; b->pending_stream = st;
+  if (n == 0) return 0;
   MsmPlan p = make_plan(n, b->pre_c);
   if (int rc = ensure_ws<C>(b, n, p)) return rc;
   g_last_plan[0] = p.c; g_last_plan[1] = p.W; g_last_plan[2] = p.pre; g_last_plan[3] = (int)p.T;
@@ -212,8 +211,6 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
   // with the window table the sorted entries carry absolute table rows (w * n_total + base_offset + i)
   const uint32_t* d_aff = p.pre ? b->d_aff : b->d_aff + base_offset * aff_words<C>();
   const uint8_t* d_inf = b->d_inf + base_offset;
-  const size_t PW = proj_words<C>();
-
   HIP_TRY(hipEventRecord(b->ev[0], st));
   HIP_TRY(hipMemsetAsync(b->d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
   const unsigned gb = (unsigned)((n + 255) / 256);
@@ -274,9 +271,22 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[3], st));
   HIP_TRY(hipMemcpyAsync(b->h_wire_out, b->d_wire_out, sizeof(uint64_t) * PWW * (size_t)NS, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventRecord(b->ev[4], st));
+  b->pending_sets = (int)NS; b->pending_c = p.c;
+  return 0;
+}
+
+template <class C, class HC>
+int msm_finish_t(mnt753_bases* b, uint64_t* out) {
+  if (!b->pending) return set_error(MNT753_EINVAL, "msm_finish: no MSM in flight on this base set");
+  b->pending = 0;
+  if (b->pending_n == 0) {
+    host::HPoint<HC>::zero().to_wire(out);
+    return 0;
+  }
+  HIP_TRY(hipEventSynchronize(b->ev[4]));
   auto t0 = std::chrono::steady_clock::now();
-  horner_host<HC>(b->h_wire_out, (int)NS, p.c, out);   // one point with the window table: a copy
+  horner_host<HC>(b->h_wire_out, b->pending_sets, b->pending_c, out);   // one point with the window table: a copy
   auto t1 = std::chrono::steady_clock::now();
   float ms;
   HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1])); g_last_timing[1] = ms;
@@ -284,8 +294,14 @@ int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scal
   HIP_TRY(hipEventElapsedTime(&ms, b->ev[2], b->ev[3])); g_last_timing[3] = ms;
   g_last_timing[4] = std::chrono::duration<float, std::milli>(t1 - t0).count();
   HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[3])); g_last_timing[0] = ms + g_last_timing[4];
-  (void)PW;
   return 0;
+}
+
+template <class C, class HC>
+int msm_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n, uint64_t* out,
+          hipStream_t st) {
+  if (int rc = msm_start_t<C, HC>(b, base_offset, scalars, scalars_on_device, n, st)) { b->pending = 0; return rc; }
+  return msm_finish_t<C, HC>(b, out);
 }
 
 }  // namespace

@@ -37,5 +37,9 @@ struct mnt753_bases {
   uint32_t* d_wire_out = nullptr;
   uint64_t* h_wire_out = nullptr;   // pinned
   uint64_t* d_scalars_stage = nullptr;
+  int pending = 0, pending_sets = 0, pending_c = 0;   // an MSM enqueued by msm_start, not yet collected
+  size_t pending_n = 0;
+  hipStream_t pending_stream = nullptr, own_stream = nullptr;
+  hipEvent_t ev_dep = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };

@@ -73,6 +73,9 @@ void run_prover(const char* params_path, const char* input_path, const char* out
   typename B::G1* evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
   auto w_off = B::vector_Fr_offset(w, primary_input_size + 1);
   typename B::G1* evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
+  // the five MSMs run concurrently on their base sets' streams; touching the results waits for them
+  (void)B::G1_words(evaluation_At); (void)B::G1_words(evaluation_Bt1); (void)B::G2_words(evaluation_Bt2);
+  (void)B::G1_words(evaluation_Ht); (void)B::G1_words(evaluation_Lt);
   auto t_msm = clk::now();
 
   auto r = B::input_r(input);
@@ -83,7 +86,7 @@ void run_prover(const char* params_path, const char* input_path, const char* out
   B::groth16_output_write(evaluation_At, evaluation_Bt2, C, output_path);
   auto t_out = clk::now();
   if (!g_quiet) {
-    printf("compute_H: %.3fs\nmultiexp (5): %.3fs\nC = Ht + Lt + r*Bt1: %.3fs\ngpu: %.3fs\nstore: %.3fs\n", secs(t_in, t_h), secs(t_h, t_msm),
+    printf("compute_H: %.3fs\nmultiexp (5, concurrent streams): %.3fs\nC = Ht + Lt + r*Bt1: %.3fs\ngpu: %.3fs\nstore: %.3fs\n", secs(t_in, t_h), secs(t_h, t_msm),
            secs(t_msm, t_c), secs(t_in, t_c), secs(t_c, t_out));
     printf("Total time from input to output: %.3fs\n", secs(t_main, t_out));
     printf("Total wall (incl. load params): %.3fs\n", secs(t0, t_out));

@@ -44,8 +44,9 @@ using namespace mnt753_hip_detail;
 
 template <int CURVE> struct mnt753_hip_impl<CURVE>::evaluation_domain { std::shared_ptr<DomainHolder> data; };
 template <int CURVE> struct mnt753_hip_impl<CURVE>::field { uint64_t data[12]; };
-template <int CURVE> struct mnt753_hip_impl<CURVE>::G1 { uint64_t data[36]; };
-template <int CURVE> struct mnt753_hip_impl<CURVE>::G2 { uint64_t data[108]; };  // 72 used on MNT4753, 108 on MNT6753
+// G1 / G2 returned by multiexp_* are lazy: the MSM is in flight on its base set's stream until the value is first used
+template <int CURVE> struct mnt753_hip_impl<CURVE>::G1 { uint64_t data[36]; std::shared_ptr<BaseSetHolder> pending; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::G2 { uint64_t data[108]; std::shared_ptr<BaseSetHolder> pending; };  // 72 used on MNT4753, 108 on MNT6753
 template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
   std::shared_ptr<DeviceBuffer> data;
   size_t size;     // elements in the underlying buffer
@@ -111,10 +112,18 @@ public:
 
 #define HIP_B mnt753_hip_impl<CURVE>
 
+template <class P> static void resolve(P* p) {
+  if (p->pending) {
+    check(mnt753_msm_finish(p->pending->h, p->data), "mnt753_msm_finish");
+    p->pending.reset();
+  }
+}
+
 template <int CURVE> void HIP_B::init_public_params() { check(mnt753_init(0), "mnt753_init"); }
 
 template <int CURVE> void HIP_B::print_G1(G1* a) {
   uint64_t aff[24];
+  resolve(a);
   check(mnt753_point_to_affine(CURVE, MNT753_G1, a->data, aff), "mnt753_point_to_affine");
   printf("G1 affine (Montgomery limbs, little-endian):\n x =");
   for (int i = 11; i >= 0; --i) printf(" %016llx", (unsigned long long)aff[i]);
@@ -125,6 +134,7 @@ template <int CURVE> void HIP_B::print_G1(G1* a) {
 template <int CURVE> void HIP_B::print_G2(G2* a) {
   const size_t w = mnt753_affine_words(CURVE, MNT753_G2);
   uint64_t aff[72];
+  resolve(a);
   check(mnt753_point_to_affine(CURVE, MNT753_G2, a->data, aff), "mnt753_point_to_affine");
   printf("G2 affine (Montgomery limbs, little-endian), %zu coefficients:\n", w / 12);
   for (size_t k = 0; k < w / 12; ++k) {
@@ -142,11 +152,13 @@ template <int CURVE> typename HIP_B::evaluation_domain* HIP_B::get_evaluation_do
 
 template <int CURVE> typename HIP_B::G1* HIP_B::G1_add(G1* a, G1* b) {
   G1* r = new G1();
+  resolve(a); resolve(b);
   check(mnt753_point_add(CURVE, MNT753_G1, a->data, b->data, r->data), "mnt753_point_add");
   return r;
 }
 template <int CURVE> typename HIP_B::G1* HIP_B::G1_scale(field* a, G1* b) {
   G1* r = new G1();
+  resolve(b);
   check(mnt753_point_scale(CURVE, MNT753_G1, a->data, b->data, r->data), "mnt753_point_scale");
   return r;
 }
@@ -164,14 +176,11 @@ template <int CURVE> void HIP_B::vector_Fr_copy_into(vector_Fr* src, vector_Fr* 
   // MNT4753: dst[i] = src[i] ignoring offsets (prover_reference_functions.cpp:209-212);
   // MNT6753: dst[i] = src[i + src->offset]            (:515-520)
   const uint64_t* s = reinterpret_cast<const uint64_t*>(src->data->ptr) + (CURVE == 1 ? 12 * src->offset : 0);
-  std::vector<uint64_t> tmp(12 * length);   // D2D through the ABI's two copies keeps the ABI minimal; length <= 2^20
-  check(mnt753_copy_d2h(tmp.data(), s, 96 * length), "mnt753_copy_d2h");
-  check(mnt753_copy_h2d(dst->data->ptr, tmp.data(), 96 * length), "mnt753_copy_h2d");
+  check(mnt753_copy_d2d(dst->data->ptr, s, 96 * length), "mnt753_copy_d2d");
 }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_zeros(size_t length) {
   auto b = std::make_shared<DeviceBuffer>(96 * length);
-  std::vector<uint64_t> z(12 * length, 0);
-  check(mnt753_copy_h2d(b->ptr, z.data(), 96 * length), "mnt753_copy_h2d");
+  check(mnt753_dev_memset(b->ptr, 0, 96 * length), "mnt753_dev_memset");
   return new vector_Fr{b, length, 0};
 }
 
@@ -191,12 +200,14 @@ template <int CURVE> size_t HIP_B::domain_get_m(evaluation_domain* domain) { ret
 
 template <int CURVE> typename HIP_B::G1* HIP_B::multiexp_G1(vector_Fr* scalar_start, vector_G1* g_start, size_t length) {
   G1* r = new G1();
-  check(mnt753_msm(g_start->data->h, 0, scalar_start->ptr(), 1, length, r->data, nullptr), "mnt753_msm(G1)");
+  check(mnt753_msm_start(g_start->data->h, 0, scalar_start->ptr(), 1, length, nullptr), "mnt753_msm_start(G1)");
+  r->pending = g_start->data;
   return r;
 }
 template <int CURVE> typename HIP_B::G2* HIP_B::multiexp_G2(vector_Fr* scalar_start, vector_G2* g_start, size_t length) {
   G2* r = new G2();
-  check(mnt753_msm(g_start->data->h, 0, scalar_start->ptr(), 1, length, r->data, nullptr), "mnt753_msm(G2)");
+  check(mnt753_msm_start(g_start->data->h, 0, scalar_start->ptr(), 1, length, nullptr), "mnt753_msm_start(G2)");
+  r->pending = g_start->data;
   return r;
 }
 
@@ -222,8 +233,8 @@ template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_L(groth16_params* 
 template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_H(groth16_params* p) { return new vector_G1{p->H}; }
 template <int CURVE> typename HIP_B::vector_G2* HIP_B::params_B2(groth16_params* p) { return new vector_G2{p->B2}; }
 
-template <int CURVE> void HIP_B::delete_G1(G1* a) { delete a; }
-template <int CURVE> void HIP_B::delete_G2(G2* a) { delete a; }
+template <int CURVE> void HIP_B::delete_G1(G1* a) { if (a) resolve(a); delete a; }
+template <int CURVE> void HIP_B::delete_G2(G2* a) { if (a) resolve(a); delete a; }
 template <int CURVE> void HIP_B::delete_vector_Fr(vector_Fr* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_G1(vector_G1* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_G2(vector_G2* a) { delete a; }
@@ -235,6 +246,7 @@ template <int CURVE> void HIP_B::delete_evaluation_domain(evaluation_domain* a) 
 template <int CURVE> void HIP_B::groth16_output_write(G1* A, G2* B, G1* C, const char* output_path) {
   const size_t g2w = mnt753_affine_words(CURVE, MNT753_G2);
   uint64_t a[24], b[72], c[24];
+  resolve(A); resolve(B); resolve(C);
   check(mnt753_point_to_affine(CURVE, MNT753_G1, A->data, a), "mnt753_point_to_affine(A)");
   check(mnt753_point_to_affine(CURVE, MNT753_G2, B->data, b), "mnt753_point_to_affine(B)");
   check(mnt753_point_to_affine(CURVE, MNT753_G1, C->data, c), "mnt753_point_to_affine(C)");
@@ -252,8 +264,8 @@ template <int CURVE> typename HIP_B::vector_Fr* HIP_B::compute_H_fused(evaluatio
   check(mnt753_compute_h(domain->data->h, ca->ptr(), cb->ptr(), cc->ptr(), reinterpret_cast<uint64_t*>(h->ptr), nullptr), "mnt753_compute_h");
   return new vector_Fr{h, m + 1, 0};
 }
-template <int CURVE> const uint64_t* HIP_B::G1_words(const G1* a) { return a->data; }
-template <int CURVE> const uint64_t* HIP_B::G2_words(const G2* a) { return a->data; }
+template <int CURVE> const uint64_t* HIP_B::G1_words(const G1* a) { resolve(const_cast<G1*>(a)); return a->data; }
+template <int CURVE> const uint64_t* HIP_B::G2_words(const G2* a) { resolve(const_cast<G2*>(a)); return a->data; }
 
 template class mnt753_hip_impl<0>;
 template class mnt753_hip_impl<1>;

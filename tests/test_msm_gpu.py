@@ -106,6 +106,29 @@ def test_scalars_on_device_and_reuse(gpu):
     bs.close()
 
 
+def test_async_start_finish_concurrent_base_sets(gpu):
+    """mnt753_msm_start / _finish: several base sets in flight at once (the five MSMs of one proof), results identical
+    to the synchronous call; a second start on a busy base set is refused."""
+    n = 3000
+    sc = gpu.synth_scalars(0, 81, n)
+    d = gpu.DeviceBuffer.from_numpy(sc)
+    sets = [(0, 1, 82), (0, 1, 83), (0, 2, 84)]
+    bases = [gpu.BaseSet(c, g, gpu.synth_points(c, g, seed, n)) for c, g, seed in sets]
+    sync = [gpu.point_to_affine(c, g, b.msm(d.ptr.value, n=n, on_device=True)) for (c, g, _), b in zip(sets, bases)]
+    for b in bases:
+        b.msm_start(d.ptr.value, n)
+    with pytest.raises(gpu.Mnt753Error):
+        bases[0].msm_start(d.ptr.value, n)
+    for (c, g, seed), b, ref in zip(sets, bases, sync):
+        got = gpu.point_to_affine(c, g, b.msm_finish())
+        assert np.array_equal(got, ref)
+        assert np.array_equal(got, gpu.point_to_affine(c, g, gpu.synth_expected_msm(c, g, seed, sc)))
+    with pytest.raises(gpu.Mnt753Error):
+        bases[0].msm_finish()
+    for b in bases:
+        b.close()
+
+
 def test_full_size_2pow20_g1_mnt4753(gpu):
     """BASELINE config[1]: 2^20 G1 bases.  Exact check through the discrete logs of the synthetic bases
     (sum_k s_k e_k mod r) * G, plus additivity MSM(s) + MSM(t) == MSM(s + t) as a size-independent property."""
