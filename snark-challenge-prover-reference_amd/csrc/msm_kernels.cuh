@@ -29,6 +29,15 @@ namespace mnt753 {
 constexpr int FPS_WORDS = 28;            // storage words per base-field element (27 limbs + pad), 112 B
 constexpr uint32_t EDGE_NONE = 0xffffffffu;
 
+// waves per SIMD requested for the point-arithmetic kernels: G1 keeps its whole state in the 512-register file at one
+// wave per SIMD; the Fq2 / Fq3 kernels spill to scratch whatever the budget, and two waves per SIMD (256 registers) were measured 3x slower,
+// so they also run one wave per SIMD (MNT753_G2_WAVES to override at build time)
+#ifndef MNT753_G2_WAVES
+#define MNT753_G2_WAVES 1
+#endif
+template <class C>
+constexpr int vm_waves() { return C::F::DEG == 1 ? 1 : MNT753_G2_WAVES; }
+
 // ---- storage helpers ---------------------------------------------------------------------
 template <int M>
 __device__ __forceinline__ void fp_load(Fp<M>& r, const uint32_t* p) {
@@ -312,7 +321,7 @@ static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restric
 // bucket -> written to buckets[].  The first and the last run may continue in a neighbouring lane
 // -> written to edges[2t], edges[2t+1] with their bucket ids.
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_bucket_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ offsets, uint32_t n_buckets,
                                                              uint32_t* __restrict__ buckets, uint32_t* __restrict__ edges,
                                                              uint32_t* __restrict__ edge_bucket, uint32_t T, uint32_t n_lanes) {
@@ -404,7 +413,7 @@ __device__ __forceinline__ void xyzz_store(uint32_t* p, const XyzzAcc<C>& A) {
 }
 
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_bucket_accumulate_u(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate_u(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                                const uint32_t* __restrict__ offsets, uint32_t n_buckets,
                                                                uint32_t* __restrict__ raw_buckets, uint32_t* __restrict__ raw_edges,
                                                                uint32_t* __restrict__ edge_bucket, uint8_t* __restrict__ bucket_state,
@@ -520,7 +529,7 @@ __device__ __forceinline__ int add_pc(Proj<C>& P, const Proj<C>& Q) {
 // (sum into tmp, copy back) so that no slot is read while it is rewritten; a device flag lets the levels
 // after the last useful one exit at once.
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_edge_level_sum(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
+__global__ void __launch_bounds__(256, vm_waves<C>()) k_edge_level_sum(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
                                                           uint32_t* __restrict__ tmp, uint32_t n_slots, uint32_t dist,
                                                           uint32_t* __restrict__ flags, uint32_t level) {
   if (level > 0 && flags[level - 1] == 0) return;   // no run longer than dist/1: nothing left to do
@@ -572,7 +581,7 @@ __global__ void __launch_bounds__(256) k_edge_finish(const uint32_t* __restrict_
 // diverges on the step loop and the kernel has ONE pt_vm call site; run / acc / R live in a small
 // per-lane HBM workspace (3 points, ~1 KB of traffic per ~50 us group operation).
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_bucket_reduce(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_reduce(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ tmp, uint32_t nb,
                                                          uint32_t L, uint32_t n_chunks_total, int kbits) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -633,7 +642,7 @@ __global__ void __launch_bounds__(256, 1) k_bucket_reduce(const uint32_t* __rest
 // ---- per-window tree sum ----------------------------------------------------------------------------
 // in: [W][n_in] points, out: [W][n_out], n_out = ceil(n_in / R); lane sums R consecutive points
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_tree_sum(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t W,
+__global__ void __launch_bounds__(256, vm_waves<C>()) k_tree_sum(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t W,
                                                     uint32_t n_in, uint32_t n_out, uint32_t R) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= W * n_out) return;

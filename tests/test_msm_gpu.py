@@ -106,6 +106,25 @@ def test_scalars_on_device_and_reuse(gpu):
     bs.close()
 
 
+def test_skewed_scalars_large(gpu):
+    """Real witnesses repeat scalars.  All-equal / two-valued / mostly 0-1 scalar vectors put ~N entries into a handful
+    of buckets: the lane-balanced accumulation and the pointer-jumping edge reduction must stay exact (and bounded)."""
+    n = 1 << 15
+    pts = gpu.synth_points(0, 1, 91, n)
+    rnd = gpu.synth_scalars(0, 92, n)
+    one = gpu.api.mont_one(0)
+    bs = gpu.BaseSet(0, 1, pts)
+    cases = [np.tile(rnd[0], (n, 1)), np.where((np.arange(n) % 2)[:, None] == 0, rnd[0], rnd[1])]
+    z = np.zeros_like(rnd); z[::2] = one; z[1::16] = rnd[1::16]
+    cases.append(z)
+    for sc in cases:
+        sc = np.ascontiguousarray(sc)
+        got = gpu.point_to_affine(0, 1, bs.msm(sc))
+        assert np.array_equal(got, gpu.point_to_affine(0, 1, gpu.synth_expected_msm(0, 1, 91, sc)))
+        assert gpu.msm_last_timing()["total_ms"] < 200
+    bs.close()
+
+
 def test_async_start_finish_concurrent_base_sets(gpu):
     """mnt753_msm_start / _finish: several base sets in flight at once (the five MSMs of one proof), results identical
     to the synchronous call; a second start on a busy base set is refused."""
