@@ -67,11 +67,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # BENCH_SHARE_GPU=1 (development only): all ranks share GPU 0 and exchange over gloo, to exercise the N > 1 flow
+    # on a single-GPU box; the real multi-GPU run is one rank per GPU over RCCL.
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-    pkg.init(local_rank)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    pkg.init(dev_index)
 
     n = 1 << args.log_n
     # rank g owns slice g of an (world * n)-point MSM: distinct seeds per rank
@@ -83,7 +90,7 @@ def main():
 
     def step():
         local = bases.msm(d_sc.data_ptr(), n=n, on_device=True, stream=stream)
-        return pkg.parallel.msm_sharded(pkg.api, 0, 1, local, device)
+        return pkg.parallel.msm_sharded(pkg.api, 0, 1, local, None if share else device)
 
     for _ in range(args.warmup):
         out = step()
@@ -101,13 +108,13 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # parity of what was just timed: every rank's slice through its discrete logs, folded like the timed path
     exp_local = pkg.synth_expected_msm(0, 1, 42 + 1000 * rank, sc)
-    exp = pkg.parallel.msm_sharded(pkg.api, 0, 1, exp_local, device)
+    exp = pkg.parallel.msm_sharded(pkg.api, 0, 1, exp_local, None if share else device)
     ok = bool(np.array_equal(pkg.point_to_affine(0, 1, out), pkg.point_to_affine(0, 1, exp)))
 
     if rank == 0:

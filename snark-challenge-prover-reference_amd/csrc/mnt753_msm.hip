@@ -32,6 +32,7 @@ int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_dev
 
 int mnt753_bases_free(mnt753_bases* b) {
   if (!b) return 0;
+  if (b->pending && b->pending_n) (void)hipStreamSynchronize(b->pending_stream);   // never free buffers under a running MSM
   msm_free_workspace(b);
   if (b->d_aff) (void)hipFree(b->d_aff);
   if (b->d_inf) (void)hipFree(b->d_inf);
