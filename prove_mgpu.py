@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""prove_mgpu.py -- the whole Groth16 prove sharded over the GPUs of one node.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        prove_mgpu.py MNT4753|MNT6753 compute <params> <input> <output>
+    python prove_mgpu.py ...                      (N = 1)
+
+Same files and same proof bytes as `./main <curve> compute ...` of the reference and as the single-GPU `main_hip`.
+Decomposition = the reference's own OpenMP chunking of an MSM (multiexp.tcc:402-441) lifted to GPUs:
+
+  * rank g keeps the slice [lo_g, hi_g) of each of the five base vectors (A, B1, B2, L, H) resident in its HBM,
+    with its window table; parameter loading is outside the timed window (libsnark/main.cpp:201-203);
+  * every rank reads the (small) input and runs compute_H itself -- the FFT is not sharded: 100 MB fit one GPU and a
+    distributed NTT would move the whole vector over xGMI for ~3 % of the work;
+  * the five local MSMs run concurrently on their base sets' streams (mnt753_msm_start / _finish);
+  * ONE all_gather per proof carries the five partial points of every rank (5 x 36..108 u64 -- latency bound);
+    every rank folds them in rank order, rank 0 finishes C = Ht + Lt + r*Bt1 and writes the proof.
+
+PyTorch is plumbing: torch.distributed (backend nccl = RCCL) and nothing else.  PROVE_SHARE_GPU=1 (development) lets all
+ranks share GPU 0 over gloo so the flow can be exercised on a single-GPU box.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def read_slice(path, offset_bytes, n_rows, row_words):
+    return np.fromfile(path, dtype=np.uint64, count=n_rows * row_words, offset=offset_bytes).reshape(n_rows, row_words)
+
+
+def main():
+    if len(sys.argv) < 6 or sys.argv[2] != "compute":
+        raise SystemExit("usage: prove_mgpu.py MNT4753|MNT6753 compute <params> <input> <output>")
+    curve = {"MNT4753": 0, "MNT6753": 1}[sys.argv[1]]
+    params_path, input_path, output_path = sys.argv[3:6]
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    share = os.environ.get("PROVE_SHARE_GPU") == "1"
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    dist = None
+    device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            device = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=device)
+    dev_index = 0 if share else local_rank
+    pkg.init(dev_index)
+
+    g1w, g2w = pkg.affine_words(curve, 1), pkg.affine_words(curve, 2)
+    t0 = time.perf_counter()
+    d, m = (int(v) for v in np.fromfile(params_path, dtype=np.uint64, count=2))
+    # file layout: d, m, A[m+1] G1, B1[m+1] G1, B2[m+1] G2, L[m-1] G1, H[d] G1   (generate_parameters.cpp:60-85)
+    layout = [("A", 1, g1w, m + 1), ("B1", 1, g1w, m + 1), ("B2", 2, g2w, m + 1), ("L", 1, g1w, m - 1), ("H", 1, g1w, d)]
+    sets, spans, off = {}, {}, 16
+    for name, group, words, n in layout:
+        lo, hi = pkg.parallel.shard_range(n, rank, world)
+        sets[name] = pkg.BaseSet(curve, group, read_slice(params_path, off + lo * words * 8, hi - lo, words))
+        spans[name] = (lo, hi)
+        off += n * words * 8
+    if world > 1:
+        dist.barrier()
+    t_params = time.perf_counter()
+
+    # ---- timed window: input load + compute + output write (main.cpp:203-270) ----
+    # input file: w[m+1], ca[d+1], cb[d+1], cc[d+1], r   (generate_parameters.cpp:88-108)
+    w = np.fromfile(input_path, dtype=np.uint64, count=12 * (m + 1))
+    abc = [np.fromfile(input_path, dtype=np.uint64, count=12 * (d + 1), offset=96 * (m + 1) + k * 96 * (d + 1)) for k in range(3)]
+    r = np.fromfile(input_path, dtype=np.uint64, count=12, offset=96 * (m + 1) + 3 * 96 * (d + 1))
+    d_w = pkg.DeviceBuffer.from_numpy(w)
+    d_abc = [pkg.DeviceBuffer.from_numpy(v) for v in abc]
+    t_in = time.perf_counter()
+
+    dom = pkg.Domain(curve, d + 1)
+    d_h = pkg.DeviceBuffer(96 * (d + 2))
+    dom.compute_h(d_abc[0].ptr.value, d_abc[1].ptr.value, d_abc[2].ptr.value, d_h.ptr.value)
+
+    # the five local MSMs, concurrently; scalar slices follow the base slices
+    # (A, B1, B2: w[i]; L: w[2 + i] = vector_Fr_offset(w, primary_input_size + 1); H: coefficients_for_H[i])
+    scal = {"A": (d_w, 0), "B1": (d_w, 0), "B2": (d_w, 0), "L": (d_w, 2), "H": (d_h, 0)}
+    for name, _, _, _ in layout:
+        buf, shift = scal[name]
+        lo, hi = spans[name]
+        sets[name].msm_start(buf.ptr.value + 96 * (lo + shift), hi - lo)
+    partial = {name: sets[name].msm_finish() for name, _, _, _ in layout}
+    t_msm = time.perf_counter()
+
+    # one exchange per proof: the five partial points of this rank
+    flat = np.concatenate([partial[name] for name, _, _, _ in layout])
+    if world > 1:
+        gathered = pkg.parallel.all_gather_points(flat, device)
+    else:
+        gathered = [flat]
+    total, pos = {}, 0
+    for name, group, _, _ in layout:
+        pw = pkg.projective_words(curve, group)
+        total[name] = pkg.parallel.fold_partials(pkg.api, curve, group, [g[pos:pos + pw] for g in gathered])
+        pos += pw
+    t_fold = time.perf_counter()
+
+    if rank == 0:
+        scaled = pkg.point_scale(curve, 1, r, total["B1"])
+        c = pkg.point_add(curve, 1, total["H"], pkg.point_add(curve, 1, total["L"], scaled))
+        with open(output_path, "wb") as f:
+            pkg.point_to_affine(curve, 1, total["A"]).tofile(f)
+            pkg.point_to_affine(curve, 2, total["B2"]).tofile(f)
+            pkg.point_to_affine(curve, 1, c).tofile(f)
+        t_out = time.perf_counter()
+        print(json.dumps({"curve": sys.argv[1], "n_gpus": world, "d": d, "m": m,
+                          "load_params_s": t_params - t0, "load_inputs_s": t_in - t_params,
+                          "compute_h_and_msm_s": t_msm - t_in, "exchange_and_fold_s": t_fold - t_msm,
+                          "total_input_to_output_s": t_out - t_params}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,30 @@ def test_synthetic_set_vs_oracle(gpu, curve, log2_d, tmp_path):
     assert filecmp.cmp(out_gpu, out_cpu, shallow=False)
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("world", [1, 2])
+def test_multi_gpu_driver_reference_proofs(gpu, curve, world, tmp_path):
+    """prove_mgpu.py (base vectors sliced over ranks, one all_gather of partial points per proof) reproduces the
+    reference's proof bytes.  world = 2 shares the single test GPU over gloo (PROVE_SHARE_GPU=1): same code path as
+    one rank per GPU over RCCL except for the backend."""
+    import socket
+    import sys
+    params, inp, expected = G.e2e_paths(curve)
+    out = str(tmp_path / "proof.bin")
+    script = os.path.join(O.ROOT, "prove_mgpu.py")
+    env = dict(os.environ, PROVE_SHARE_GPU="1")
+    if world == 1:
+        cmd = [sys.executable, script, NAME[curve], "compute", params, inp, out]
+    else:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, NAME[curve], "compute", params, inp, out]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert filecmp.cmp(out, expected, shallow=False)
+    assert '"total_input_to_output_s"' in r.stdout
+
+
 def test_cli_errors(gpu, tmp_path):
     r = subprocess.run([EXE, "MNT4753", "compute", "/nonexistent", "/nonexistent", str(tmp_path / "o")], capture_output=True, text=True)
     assert r.returncode == 1 and "cannot open" in r.stderr
