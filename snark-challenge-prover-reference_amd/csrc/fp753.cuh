@@ -155,24 +155,32 @@ HD void fp_canon(Fp<M>& r, const Fp<M>& a) {
   for (int i = 0; i < NL; ++i) r.l[i] = bw < 0 ? a.l[i] : d[i];
 }
 
-// r = k*a for a small non-negative integer k (curve / twist coefficients 2, 11, 13, 26, 121):
-// binary double-and-add on the lazy representation; ~2*log2(k) additions, no multiplier instance.
+// r = k*a mod p (lazily, r in [0, 2p)) for a small integer k < 256 and a in [0, 2p): curve / twist coefficients and
+// extension-field non-residues (2, 11, 13, 26, 121).
+//   V = k*a is formed limb-wise (no reduction needed: V < 2^762), the quotient q = floor(V / p) is estimated from the
+//   top limb:  q' = floor( floor(V / 2^728) / (floor(p / 2^728) + 1) )  which satisfies  q - 1 <= q' <= q  (the relative
+//   error of both truncations is < 2^-16), so V - q' p lies in [0, 2p) and needs no conditional subtraction.
+// ~260 instructions; the previous double-and-add over lazy additions took ~1250 for k = 13.
 template <int M>
 HD void fp_mul_small(Fp<M>& r, const Fp<M>& a, unsigned k) {
-  Fp<M> acc, base = a;
-  fp_zero(acc);
-  bool have = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma nounroll
-#endif
-  for (; k != 0; k >>= 1) {
-    if (k & 1) {
-      if (have) fp_add(acc, acc, base);
-      else { acc = base; have = true; }
-    }
-    if (k > 1) fp_add(base, base, base);
+  uint32_t t[NL + 1];
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    c += (uint64_t)a.l[i] * k;
+    t[i] = (uint32_t)c & LMASK;
+    c >>= LB;
   }
-  r = acc;
+  t[NL] = (uint32_t)c;
+  const uint64_t vh = ((uint64_t)t[NL] << LB) | t[NL - 1];
+  const uint32_t q = (uint32_t)(vh / (uint64_t)(FPC[M].p[NL - 1] + 1u));   // division by a compile-time constant
+  int64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    s += (int64_t)t[i] - (int64_t)((uint64_t)q * FPC[M].p[i]);
+    r.l[i] = (uint32_t)s & LMASK;
+    s >>= LB;   // arithmetic shift: s carries the (signed) borrow
+  }
 }
 
 // ---- wire-format conversion -------------------------------------------------------------

@@ -144,8 +144,37 @@ template <class C, class HC> bool chain(const char* name, const char* path) {
   }
   return all;
 }
+// fp_mul_small against repeated lazy addition, on random and extreme inputs
+template <int M> bool check_mul_small() {
+  bool all = true;
+  uint64_t st = 12345 + M;
+  auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(st >> 33); };
+  for (int it = 0; it < 4000; ++it) {
+    Fp<M> a;
+    for (int i = 0; i < NL; ++i) a.l[i] = rnd() & LMASK;
+    a.l[NL - 1] &= 0x1ffffff;                       // < 2^753
+    if (it % 5 == 1) for (int i = 0; i < NL; ++i) a.l[i] = FPC[M].p2[i] - (i == 0 ? 1 : 0);   // 2p - 1
+    if (it % 5 == 2) fp_zero(a);
+    if (it % 5 == 3) for (int i = 0; i < NL; ++i) a.l[i] = FPC[M].p[i];                         // p
+    Fp<M> chk; fp_reduce2p(chk, a.l); a = chk;      // into [0, 2p)
+    unsigned k = (it % 7 == 0) ? 121u : (it % 7 == 1 ? 13u : (it % 7 == 2 ? 255u : 1u + rnd() % 200u));
+    Fp<M> got, ref, c1, c2;
+    fp_mul_small(got, a, k);
+    fp_zero(ref);
+    for (unsigned j = 0; j < k; ++j) fp_add(ref, ref, a);
+    fp_canon(c1, got); fp_canon(c2, ref);
+    bool in_range = true;   // got < 2p
+    { Fp<M> tmp; uint32_t d[NL]; int32_t bw = 0; for (int i = 0; i < NL; ++i) { int32_t t = (int32_t)got.l[i] - (int32_t)FPC[M].p2[i] + bw; d[i] = t & LMASK; bw = t >> LB; } in_range = bw < 0; (void)tmp; (void)d; }
+    bool limbs_ok = true; for (int i = 0; i < NL; ++i) limbs_ok &= got.l[i] <= LMASK;
+    if (memcmp(c1.l, c2.l, sizeof(c1.l)) != 0 || !in_range || !limbs_ok) { printf("mul_small M=%d k=%u it=%d MISMATCH\n", M, k, it); all = false; }
+  }
+  printf("mul_small M=%d: %s\n", M, all ? "OK" : "MISMATCH");
+  return all;
+}
 int main() {
   bool ok = true;
+  ok &= check_mul_small<0>();
+  ok &= check_mul_small<1>();
   ok &= check<Mnt4G1, host::HMnt4G1>("mnt4 g1", "tests/golden/group_mnt4_g1.bin");
   ok &= check<Mnt6G1, host::HMnt6G1>("mnt6 g1", "tests/golden/group_mnt6_g1.bin");
   ok &= check<Mnt4G2, host::HMnt4G2>("mnt4 g2", "tests/golden/group_mnt4_g2.bin");
