@@ -26,6 +26,10 @@ int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_dev
   if (curve == MNT753_CURVE_MNT4753) rc = group == MNT753_G1 ? bases_create_mnt4g1(b, affine, on_device, n) : bases_create_mnt4g2(b, affine, on_device, n);
   else rc = group == MNT753_G1 ? bases_create_mnt6g1(b, affine, on_device, n) : bases_create_mnt6g2(b, affine, on_device, n);
   if (rc) { mnt753_bases_free(b); return rc; }
+  // the base set's own stream for mnt753_msm_start (creating a stream costs ~8 ms: do it here, at parameter-load time)
+  if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) b->own_stream = nullptr;
+  if (hipEventCreateWithFlags(&b->ev_dep, hipEventDisableTiming) != hipSuccess) b->ev_dep = nullptr;
+  (void)hipGetLastError();
   *out = b;
   return 0;
 }

@@ -67,9 +67,11 @@ void run_prover(const char* params_path, const char* input_path, const char* out
 
   auto pA = B::params_A(params); auto pB1 = B::params_B1(params); auto pB2 = B::params_B2(params);
   auto pH = B::params_H(params); auto pL = B::params_L(params);
+  // Same five multi-exponentiations as cuda_prover_piecewise.cu:71-81.  They are independent and B::multiexp_* only
+  // enqueues them, so the long G2 one goes first and the short G1 ones run inside its latency-bound reduction tail.
+  typename B::G2* evaluation_Bt2 = B::multiexp_G2(w, pB2, B::params_m(params) + 1);
   typename B::G1* evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
   typename B::G1* evaluation_Bt1 = B::multiexp_G1(w, pB1, B::params_m(params) + 1);
-  typename B::G2* evaluation_Bt2 = B::multiexp_G2(w, pB2, B::params_m(params) + 1);
   typename B::G1* evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
   auto w_off = B::vector_Fr_offset(w, primary_input_size + 1);
   typename B::G1* evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
