@@ -17,7 +17,7 @@ MAIN := $(PKG)/main_hip
 all: $(LIB) $(MAIN) oracle
 
 $(MAIN): $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp include/prover_hip_functions.hpp include/mnt753_hip.h $(LIB)
-	g++ -O2 -std=c++17 -o $@ $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp -L$(PKG) -lmnt753_hip -Wl,-rpath,'$$ORIGIN'
+	g++ -O2 -std=c++17 -pthread -o $@ $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp -L$(PKG) -lmnt753_hip -Wl,-rpath,'$$ORIGIN'
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)

@@ -67,6 +67,11 @@ int mnt753_copy_d2h(void* dst, const void* dev_src, size_t bytes);
 int mnt753_copy_d2d(void* dev_dst, const void* dev_src, size_t bytes);
 int mnt753_dev_memset(void* dev_dst, int value, size_t bytes);
 int mnt753_sync(void* stream);
+/* Stream `bytes` of file `path` starting at `file_offset` into device memory (double-buffered pinned staging, reads
+ * overlap the H2D copies); blocks the calling thread until the data is on the device.  Thread-safe: the wrapper's input
+ * loader calls it from a background thread while the main thread launches kernels (replaces the 6.3 M fread calls of
+ * the reference's groth16_input constructor, prover_reference_functions.cpp:48-76). */
+int mnt753_load_file_to_device(const char* path, size_t file_offset, size_t bytes, void* dev_dst);
 
 /* ---- MSM --------------------------------------------------------------------------------------
  * A base set is the device-resident, pre-converted image of a vector_G1 / vector_G2 of the parameters

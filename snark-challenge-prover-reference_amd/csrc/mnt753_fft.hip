@@ -22,6 +22,8 @@ struct mnt753_domain {
   uint32_t *cos_inv_s = nullptr;                       // g^-i / m                    (m)
   uint32_t *consts = nullptr;                          // [0] 1/m  [1] 2^12 (k1)  [2] Z^-1 * 2^-12 (k2)  [3] Z^-1
   uint32_t *work = nullptr;                            // m wire elements
+  uint32_t *stage = nullptr;                           // the seeds the tables were generated from (freed with the domain:
+                                                       // hipFree is a device-wide sync and would wait for MSMs in flight)
 };
 
 namespace {
@@ -51,8 +53,8 @@ int build_tables(mnt753_domain* d) {
   }
   put(128, Fr::one()); put(129, minv);                   // scales
   put(132, minv); put(133, two12); put(134, zinv * two12_inv); put(135, zinv);
-  uint32_t* d_stage = nullptr;
-  HIP_TRY(hipMalloc(&d_stage, stage.size() * 8));
+  HIP_TRY(hipMalloc(&d->stage, stage.size() * 8));
+  uint32_t* d_stage = d->stage;
   HIP_TRY(hipMemcpy(d_stage, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
   const size_t half = m / 2 ? m / 2 : 1;
   HIP_TRY(hipMalloc(&d->tw_fwd, half * FPS_WORDS * 4));
@@ -73,8 +75,7 @@ int build_tables(mnt753_domain* d) {
   table(d->cos_inv_s, 3, 129, m);
   hipLaunchKernelGGL((k_consts_to_internal<M>), dim3(1), dim3(64), 0, 0, d->consts, d_stage + (size_t)132 * 24, 4);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipFree(d_stage));
+  HIP_TRY(hipStreamSynchronize(nullptr));   // the tables are built on the default stream; MSM streams are not waited for
   return 0;
 }
 
@@ -171,7 +172,7 @@ int mnt753_domain_create(int curve, size_t m, mnt753_domain** out) {
 
 int mnt753_domain_free(mnt753_domain* d) {
   if (!d) return 0;
-  void* ptrs[] = {d->tw_fwd, d->tw_inv, d->cos_fwd, d->cos_fwd_s, d->cos_inv_s, d->consts, d->work};
+  void* ptrs[] = {d->tw_fwd, d->tw_inv, d->cos_fwd, d->cos_fwd_s, d->cos_inv_s, d->consts, d->work, d->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete d;
   return 0;

@@ -13,6 +13,17 @@ int g_last_plan[4] = {0, 0, 0, 0};
 }
 using namespace mnt753;
 
+namespace {
+// MSM streams run at the lowest priority the device offers: an MSM is hundreds of milliseconds of throughput work,
+// and short kernels on the default stream (the NTTs of compute_H, launched while MSMs are in flight) should be
+// scheduled ahead of its remaining workgroups.
+hipError_t create_msm_stream(hipStream_t* s) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+}
+}  // namespace
+
 extern "C" {
 
 
@@ -27,7 +38,7 @@ int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_dev
   else rc = group == MNT753_G1 ? bases_create_mnt6g1(b, affine, on_device, n) : bases_create_mnt6g2(b, affine, on_device, n);
   if (rc) { mnt753_bases_free(b); return rc; }
   // the base set's own stream for mnt753_msm_start (creating a stream costs ~8 ms: do it here, at parameter-load time)
-  if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) b->own_stream = nullptr;
+  if (create_msm_stream(&b->own_stream) != hipSuccess) b->own_stream = nullptr;
   if (hipEventCreateWithFlags(&b->ev_dep, hipEventDisableTiming) != hipSuccess) b->ev_dep = nullptr;
   (void)hipGetLastError();
   *out = b;
@@ -70,7 +81,7 @@ int mnt753_msm_start(mnt753_bases* b, size_t base_offset, const uint64_t* scalar
   hipStream_t st = (hipStream_t)stream;
   if (!st) {
     // the base set's own non-blocking stream, ordered after everything already enqueued on the default stream
-    if (!b->own_stream) HIP_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    if (!b->own_stream) HIP_TRY(create_msm_stream(&b->own_stream));
     if (!b->ev_dep) HIP_TRY(hipEventCreateWithFlags(&b->ev_dep, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->ev_dep, nullptr));
     HIP_TRY(hipStreamWaitEvent(b->own_stream, b->ev_dep, 0));

@@ -3,9 +3,13 @@
 // here every vector lives in HBM and every heavy call is a HIP kernel launch.
 #include "../../include/prover_hip_functions.hpp"
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -25,6 +29,19 @@ struct DeviceBuffer {
   ~DeviceBuffer() { if (ptr) mnt753_dev_free(ptr); }
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+};
+// one-shot readiness latch: set by the input loader thread, awaited by the first consumer of a vector
+struct Ready {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  std::string error;
+  void set(const std::string& err = std::string()) { { std::lock_guard<std::mutex> l(mu); done = true; error = err; } cv.notify_all(); }
+  void wait() {
+    std::unique_lock<std::mutex> l(mu);
+    cv.wait(l, [&] { return done; });
+    if (!error.empty()) throw std::runtime_error(error);
+  }
 };
 struct BaseSetHolder {
   mnt753_bases* h = nullptr;
@@ -51,7 +68,12 @@ template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
   std::shared_ptr<DeviceBuffer> data;
   size_t size;     // elements in the underlying buffer
   size_t offset;   // element offset honoured by multiexp / muleq / subeq (prover_reference_functions.cpp:173,254)
-  uint64_t* ptr() const { return reinterpret_cast<uint64_t*>(data->ptr) + 12 * offset; }
+  std::shared_ptr<Ready> ready;   // set for vectors of a groth16_input that is still streaming in from its file
+  // device pointer; waits (once) until the loader thread has put the vector on the device
+  uint64_t* ptr() const {
+    if (ready) ready->wait();
+    return reinterpret_cast<uint64_t*>(data->ptr) + 12 * offset;
+  }
 };
 template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G1 { std::shared_ptr<BaseSetHolder> data; };
 template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G2 { std::shared_ptr<BaseSetHolder> data; };
@@ -87,27 +109,43 @@ public:
 };
 
 // input file: w[m+1], ca[d+1], cb[d+1], cc[d+1], r   (generate_parameters.cpp:88-108, reader :48-76)
+// The constructor returns at once; a loader thread streams the four vectors to the device in file order and releases
+// them one by one, so kernels that only need w (four of the five MSMs) start while ca / cb / cc are still being read.
 template <int CURVE>
 class mnt753_hip_impl<CURVE>::groth16_input {
 public:
   std::shared_ptr<DeviceBuffer> w, ca, cb, cc;
+  std::shared_ptr<Ready> w_ready, ca_ready, cb_ready, cc_ready, r_ready;
   size_t n_w = 0, n_c = 0;
   uint64_t r[12];
+  std::thread loader;
   groth16_input(const char* path, size_t d, size_t m) {
     FILE* f = fopen(path, "rb");
     if (!f) throw std::runtime_error(std::string("cannot open input file ") + path);
     n_w = m + 1; n_c = d + 1;
-    std::vector<uint64_t> host(12 * (n_w > n_c ? n_w : n_c));
-    auto load = [&](size_t n) {
-      read_exact(f, host.data(), 96 * n, path);
-      auto b = std::make_shared<DeviceBuffer>(96 * n);
-      check(mnt753_copy_h2d(b->ptr, host.data(), 96 * n), "mnt753_copy_h2d");
-      return b;
-    };
-    w = load(n_w); ca = load(n_c); cb = load(n_c); cc = load(n_c);
-    read_exact(f, r, 96, path);
+    const size_t r_off = 96 * (n_w + 3 * n_c);
+    if (fseeko(f, (off_t)r_off, SEEK_SET) != 0 || fread(r, 1, 96, f) != 96) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
     fclose(f);
+    w = std::make_shared<DeviceBuffer>(96 * n_w);
+    ca = std::make_shared<DeviceBuffer>(96 * n_c);
+    cb = std::make_shared<DeviceBuffer>(96 * n_c);
+    cc = std::make_shared<DeviceBuffer>(96 * n_c);
+    w_ready = std::make_shared<Ready>(); ca_ready = std::make_shared<Ready>(); cb_ready = std::make_shared<Ready>();
+    cc_ready = std::make_shared<Ready>();
+    const std::string p(path);
+    struct Part { void* dst; size_t off, bytes; std::shared_ptr<Ready> ready; };
+    std::vector<Part> parts = {{w->ptr, 0, 96 * n_w, w_ready}, {ca->ptr, 96 * n_w, 96 * n_c, ca_ready},
+                               {cb->ptr, 96 * (n_w + n_c), 96 * n_c, cb_ready}, {cc->ptr, 96 * (n_w + 2 * n_c), 96 * n_c, cc_ready}};
+    loader = std::thread([p, parts]() {
+      std::string err;
+      for (const Part& part : parts) {
+        if (err.empty() && mnt753_load_file_to_device(p.c_str(), part.off, part.bytes, part.dst) != 0)
+          err = std::string("mnt753_load_file_to_device: ") + mnt753_last_error();
+        part.ready->set(err);
+      }
+    });
   }
+  ~groth16_input() { if (loader.joinable()) loader.join(); }
 };
 
 #define HIP_B mnt753_hip_impl<CURVE>
@@ -144,10 +182,22 @@ template <int CURVE> void HIP_B::print_G2(G2* a) {
   }
 }
 
-template <int CURVE> typename HIP_B::evaluation_domain* HIP_B::get_evaluation_domain(size_t d) {
+// Domains (twiddle and coset tables, ~0.5 GB of HBM at 2^20) are cached per (curve, size): creating one allocates and
+// frees device memory, which synchronises the whole device and would stall behind MSMs already in flight.  read_params
+// creates the domain for d + 1 ahead of time -- it depends on the parameters only, like the MSM window tables.
+template <int CURVE> static std::shared_ptr<DomainHolder> cached_domain(size_t d) {
+  static std::mutex mu;
+  static std::map<size_t, std::shared_ptr<DomainHolder>> cache;
+  std::lock_guard<std::mutex> l(mu);
+  auto it = cache.find(d);
+  if (it != cache.end()) return it->second;
   auto h = std::make_shared<DomainHolder>();
   check(mnt753_domain_create(CURVE, d, &h->h), "mnt753_domain_create");
-  return new evaluation_domain{h};
+  cache[d] = h;
+  return h;
+}
+template <int CURVE> typename HIP_B::evaluation_domain* HIP_B::get_evaluation_domain(size_t d) {
+  return new evaluation_domain{cached_domain<CURVE>(d)};
 }
 
 template <int CURVE> typename HIP_B::G1* HIP_B::G1_add(G1* a, G1* b) {
@@ -170,18 +220,20 @@ template <int CURVE> void HIP_B::vector_Fr_subeq(vector_Fr* a, vector_Fr* b, siz
   check(mnt753_vec_subeq(CURVE, a->ptr(), b->ptr(), size, nullptr), "mnt753_vec_subeq");
 }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_offset(vector_Fr* a, size_t offset) {
-  return new vector_Fr{a->data, a->size, offset};
+  return new vector_Fr{a->data, a->size, offset, a->ready};
 }
 template <int CURVE> void HIP_B::vector_Fr_copy_into(vector_Fr* src, vector_Fr* dst, size_t length) {
   // MNT4753: dst[i] = src[i] ignoring offsets (prover_reference_functions.cpp:209-212);
   // MNT6753: dst[i] = src[i + src->offset]            (:515-520)
+  if (src->ready) src->ready->wait();
+  if (dst->ready) dst->ready->wait();
   const uint64_t* s = reinterpret_cast<const uint64_t*>(src->data->ptr) + (CURVE == 1 ? 12 * src->offset : 0);
   check(mnt753_copy_d2d(dst->data->ptr, s, 96 * length), "mnt753_copy_d2d");
 }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_zeros(size_t length) {
   auto b = std::make_shared<DeviceBuffer>(96 * length);
   check(mnt753_dev_memset(b->ptr, 0, 96 * length), "mnt753_dev_memset");
-  return new vector_Fr{b, length, 0};
+  return new vector_Fr{b, length, 0, nullptr};
 }
 
 template <int CURVE> void HIP_B::domain_iFFT(evaluation_domain* domain, vector_Fr* a) {
@@ -214,17 +266,21 @@ template <int CURVE> typename HIP_B::G2* HIP_B::multiexp_G2(vector_Fr* scalar_st
 template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_input(const char* path, groth16_params* params) {
   return new groth16_input(path, params->d, params->m);
 }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_w(groth16_input* in) { return new vector_Fr{in->w, in->n_w, 0}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_ca(groth16_input* in) { return new vector_Fr{in->ca, in->n_c, 0}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cb(groth16_input* in) { return new vector_Fr{in->cb, in->n_c, 0}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cc(groth16_input* in) { return new vector_Fr{in->cc, in->n_c, 0}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_w(groth16_input* in) { return new vector_Fr{in->w, in->n_w, 0, in->w_ready}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_ca(groth16_input* in) { return new vector_Fr{in->ca, in->n_c, 0, in->ca_ready}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cb(groth16_input* in) { return new vector_Fr{in->cb, in->n_c, 0, in->cb_ready}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cc(groth16_input* in) { return new vector_Fr{in->cc, in->n_c, 0, in->cc_ready}; }
 template <int CURVE> typename HIP_B::field* HIP_B::input_r(groth16_input* in) {
   field* f = new field();
   memcpy(f->data, in->r, 96);
   return f;
 }
 
-template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const char* path) { return new groth16_params(path); }
+template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const char* path) {
+  groth16_params* p = new groth16_params(path);
+  (void)cached_domain<CURVE>(p->d + 1);
+  return p;
+}
 template <int CURVE> size_t HIP_B::params_d(groth16_params* p) { return p->d; }
 template <int CURVE> size_t HIP_B::params_m(groth16_params* p) { return p->m; }
 template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_A(groth16_params* p) { return new vector_G1{p->A}; }
@@ -262,7 +318,7 @@ template <int CURVE> typename HIP_B::vector_Fr* HIP_B::compute_H_fused(evaluatio
   const size_t m = mnt753_domain_size(domain->data->h);
   auto h = std::make_shared<DeviceBuffer>(96 * (m + 1));
   check(mnt753_compute_h(domain->data->h, ca->ptr(), cb->ptr(), cc->ptr(), reinterpret_cast<uint64_t*>(h->ptr), nullptr), "mnt753_compute_h");
-  return new vector_Fr{h, m + 1, 0};
+  return new vector_Fr{h, m + 1, 0, nullptr};
 }
 template <int CURVE> const uint64_t* HIP_B::G1_words(const G1* a) { resolve(const_cast<G1*>(a)); return a->data; }
 template <int CURVE> const uint64_t* HIP_B::G2_words(const G2* a) { resolve(const_cast<G2*>(a)); return a->data; }
