@@ -139,6 +139,64 @@ struct FieldFp3 {
 };
 
 // ------------------------------------------------------------------------------------------
+// Lane-split Fq2: TWO adjacent lanes (2j, 2j+1) hold one element, lane parity = component index.  Per-lane state is
+// that of a base-field element, so a G2 point operation needs the registers of a G1 one (the one-lane Fq2 VM keeps
+// ~950 dwords live and spills 1.7 KB per lane to scratch).  A product is
+//      even lane:  c0 = x0*y0 + (NR*x1)*y1        odd lane:  c1 = x1*y0 + x0*y1
+// i.e. ONE fp_mul2 per lane; the partner's operands arrive through DPP quad_perm [1,0,3,2] (v_mov_b32_dpp, no LDS).
+// Both lanes of a pair always follow the same control flow (same sorted entries, same program counter).
+// Additions, subtractions and negations are component-wise and need no exchange.
+// ------------------------------------------------------------------------------------------
+HD uint32_t pair_swap_u32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+#else
+  return v;   // host builds only need this to compile
+#endif
+}
+HD bool lane_is_odd() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (threadIdx.x & 1u) != 0;
+#else
+  return false;
+#endif
+}
+template <int M, unsigned NR>
+struct FieldFp2S {
+  using E = Fp<M>;
+  static constexpr int DEG = 2;      // components per element in memory (same layout as FieldFp2)
+  static constexpr int MOD = M;
+  static HD void mul(E& r, const E& x, const E& y) {
+    E xo, b1, b2;
+    const bool odd = lane_is_odd();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      xo.l[i] = pair_swap_u32(x.l[i]);
+      const uint32_t yo = pair_swap_u32(y.l[i]);
+      b1.l[i] = odd ? yo : y.l[i];
+      b2.l[i] = odd ? y.l[i] : yo;
+    }
+    E nx;
+    fp_mul_small(nx, xo, NR);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) xo.l[i] = odd ? xo.l[i] : nx.l[i];
+    fp_mul2(r, x, b1, xo, b2);
+  }
+  static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
+  static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
+  static HD void neg(E& r, const E& a) { fp_neg(r, a); }
+  static HD bool is_zero(const E& a) {
+    const uint32_t z = fp_is_zero(a) ? 1u : 0u;
+    return (z & pair_swap_u32(z)) != 0;
+  }
+  static HD void zero(E& r) { fp_zero(r); }
+  static HD void one(E& r) {
+    fp_one(r);
+    if (lane_is_odd()) fp_zero(r);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // Curve configurations: coordinate field F, scalar-field modulus FR, and mul_by_a.
 // ------------------------------------------------------------------------------------------
 struct Mnt4G1 {  // y^2 = x^3 + 2x + b over Fq = B          (mnt4753_init.cpp:119)
@@ -171,6 +229,17 @@ struct Mnt6G2 {  // twist over Fq3, a' = (0,0,11): mul_by_a(c0,c1,c2) = (121 c1,
   }
   static HD void coeff_a(F::E& r) { F::E o; F::one(o); mul_by_a(r, o); }   // a' = (0, 0, 11)
 };
+
+// lane-split counterpart of Mnt4G2 (same memory layout, two lanes per point)
+struct Mnt4G2S {
+  using F = FieldFp2S<MOD_B, 13u>;
+  static constexpr int FR = MOD_A;
+  static HD void mul_by_a(F::E& r, const F::E& x) { fp_mul_small(r, x, 26u); }   // (26 c0, 26 c1), component-wise
+  static HD void coeff_a(F::E& r) { F::E o; F::one(o); mul_by_a(r, o); }
+};
+// C -> its lane-split configuration (void: none, the group runs one lane per point)
+template <class C> struct SplitOf { using type = void; };
+template <> struct SplitOf<Mnt4G2> { using type = Mnt4G2S; };
 
 template <class C>
 struct Proj {

@@ -68,6 +68,49 @@ HD void fp_mul(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
   r.l[NL - 1] = (uint32_t)acc;
 }
 
+// r = (a1*b1 + a2*b2) * 2^-756 mod p with ONE Montgomery reduction: 2*729 + 729 = 2187 multiply-adds instead of the
+// 2916 of two separate products.  All four inputs in [0, 2p): the sum is < 8p^2, so r < p(8p/R' + 1) < 2p because
+// 8p < 0.89 R' for both moduli (p ~ 1.77 * 2^752).  A column holds at most 54 + 27 products < 2^57 and one carry, well
+// inside 64 bits.  This is the multiplier of the lane-split extension fields (curve753.cuh): every component of a
+// product in Fq2 is a sum of two base-field products.
+template <int M>
+HD void fp_mul2(Fp<M>& r, const Fp<M>& a1, const Fp<M>& b1, const Fp<M>& a2, const Fp<M>& b2) {
+  uint64_t acc = 0, acc2 = 0;
+  uint32_t m[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)a1.l[i] * b1.l[k - i];
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc2 += (uint64_t)a2.l[i] * b2.l[k - i];
+    acc += acc2;
+    acc2 = 0;
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += acc2;
+    acc2 = 0;
+    m[k] = ((uint32_t)acc * FPC[M].inv) & LMASK;
+    acc += (uint64_t)m[k] * FPC[M].p[0];
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)a1.l[i] * b1.l[k - i];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc2 += (uint64_t)a2.l[i] * b2.l[k - i];
+    acc += acc2;
+    acc2 = 0;
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += acc2;
+    acc2 = 0;
+    r.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+}
+
 // s (normalised limbs, value < 4p) -> r = s mod 2p, in [0, 2p)
 template <int M>
 HD void fp_reduce2p(Fp<M>& r, const uint32_t s[NL]) {

@@ -1,5 +1,6 @@
 // Host orchestration of the MSM kernels (templates; instantiated once per curve/group in msm_inst_*.hip).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
@@ -83,6 +84,24 @@ namespace {
 
 template <class C>
 int proj_w() { return proj_words<C>(); }
+
+// Lane-split accumulate (k_bucket_accumulate_s): default for the groups that have a split configuration (Fq2);
+// MNT753_MSM_ACC=vm forces the one-lane-per-point kernel.
+template <class C>
+bool use_split_acc() {
+  if (std::is_void<typename SplitOf<C>::type>::value) return false;
+  if (const char* e = getenv("MNT753_MSM_ACC")) return strcmp(e, "vm") != 0 && strcmp(e, "uniform") != 0;
+  return true;
+}
+template <class C>
+void launch_split_acc(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b) {
+  using CS = typename SplitOf<C>::type;
+  if constexpr (!std::is_void<CS>::value) {
+    const unsigned threads = p.n_lanes * (unsigned)CS::F::DEG;
+    hipLaunchKernelGGL((k_bucket_accumulate_s<CS>), dim3((threads + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
+                       p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
+  }
+}
 
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
@@ -235,6 +254,8 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
                        b->d_bucket_state, (const uint32_t*)nullptr, p.n_buckets);
     hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_raw_edges, b->d_edges,
                        (const uint8_t*)nullptr, b->d_edge_bucket, 2 * p.n_lanes);
+  } else if (use_split_acc<C>()) {
+    launch_split_acc<C>(p, st, d_aff, b);
   } else {
     hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
                        p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);

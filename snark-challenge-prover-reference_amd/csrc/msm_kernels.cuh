@@ -393,6 +393,89 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
   }
 }
 
+// ---- bucket accumulation, lane-split version (two lanes per point, FieldFp2S) -------------------------------
+// Same schedule and same outputs as k_bucket_accumulate<C> -- logical lane t = thread / 2 owns sorted entries
+// [t*T, (t+1)*T) -- but thread parity k selects the Fq2 component this lane loads, computes and stores.  Memory layout
+// of points is unchanged, so every other kernel of the pipeline is shared with the one-lane path.
+template <class CS>
+__device__ __forceinline__ void proj_store_split(uint32_t* p, const Proj<CS>& P, uint32_t k) {
+  constexpr int D = CS::F::DEG;
+  fp_store(p + k * FPS_WORDS, P.X);
+  fp_store(p + (D + k) * FPS_WORDS, P.Y);
+  fp_store(p + (2 * D + k) * FPS_WORDS, P.Z);
+}
+template <class CS>
+__global__ void __launch_bounds__(256, 1) k_bucket_accumulate_s(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                                const uint32_t* __restrict__ offsets, uint32_t n_buckets,
+                                                                uint32_t* __restrict__ buckets, uint32_t* __restrict__ edges,
+                                                                uint32_t* __restrict__ edge_bucket, uint32_t T, uint32_t n_lanes) {
+  using F = typename CS::F;
+  constexpr int D = F::DEG;
+  constexpr int AW = 2 * D * FPS_WORDS, PW = 3 * D * FPS_WORDS;
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = gt / D, k = gt % D;
+  if (t >= n_lanes) return;
+  const uint32_t total = offsets[n_buckets];
+  uint64_t e0 = (uint64_t)t * T;
+  if (e0 >= total) {
+    edge_bucket[2 * t] = EDGE_NONE;
+    edge_bucket[2 * t + 1] = EDGE_NONE;
+    return;
+  }
+  uint32_t e = (uint32_t)e0;
+  uint32_t end = (e0 + T < total) ? (uint32_t)(e0 + T) : total;
+  uint32_t lo = 0, hi = n_buckets;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offsets[mid + 1] > e) hi = mid; else lo = mid + 1;
+  }
+  uint32_t b = lo;
+  uint32_t next = offsets[b + 1];
+  bool first_run = true;
+  bool acc_zero = true;
+  Proj<CS> acc, Q;
+  pt_set_zero(acc);
+  F::one(Q.Z);
+  for (; e < end; ++e) {
+    if (e == next) {
+      if (first_run) {
+        proj_store_split<CS>(edges + (size_t)(2 * t) * PW, acc, k);
+        edge_bucket[2 * t] = b;
+        first_run = false;
+      } else {
+        proj_store_split<CS>(buckets + (size_t)b * PW, acc, k);
+      }
+      acc_zero = true;
+      do { ++b; next = offsets[b + 1]; } while (next == e);
+    }
+    uint32_t s = sorted[e];
+    const uint32_t* src = bases + (size_t)(s & 0x7fffffffu) * AW;
+    fp_load(Q.X, src + k * FPS_WORDS);
+    fp_load(Q.Y, src + (D + k) * FPS_WORDS);
+    if (s & 0x80000000u) F::neg(Q.Y, Q.Y);
+    int pc = PC_MADD;
+    if (acc_zero) {
+      acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z);
+      acc_zero = false;
+      pc = PC_END;
+    } else if (pt_is_zero(acc)) {
+      acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z);
+      pc = PC_END;
+    }
+    pt_vm<CS, false>(acc, Q, pc);
+  }
+  if (first_run) {
+    proj_store_split<CS>(edges + (size_t)(2 * t) * PW, acc, k);
+    edge_bucket[2 * t] = b;
+    pt_set_zero(acc);
+    proj_store_split<CS>(edges + (size_t)(2 * t + 1) * PW, acc, k);
+    edge_bucket[2 * t + 1] = b;
+  } else {
+    proj_store_split<CS>(edges + (size_t)(2 * t + 1) * PW, acc, k);
+    edge_bucket[2 * t + 1] = b;
+  }
+}
+
 // ---- bucket accumulation, wave-uniform version (vm_uniform.cuh) ------------------------------------------
 // Same lane schedule as k_bucket_accumulate (lane t sums sorted entries [t*T, (t+1)*T), whole buckets go to the
 // bucket array, the first / last partial run to the edge slots), but:
