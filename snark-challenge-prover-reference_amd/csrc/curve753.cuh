@@ -22,6 +22,7 @@ template <int M>
 struct FieldFp {
   using E = Fp<M>;
   static constexpr int DEG = 1;
+  static constexpr int LANES = 1;
   static constexpr int MOD = M;
   static HD void mul(E& r, const E& a, const E& b) { fp_mul(r, a, b); }
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
@@ -48,6 +49,7 @@ template <int M, unsigned NR>
 struct FieldFp2 {
   using E = Fp2E<M>;
   static constexpr int DEG = 2;
+  static constexpr int LANES = 1;
   static constexpr int MOD = M;
   static HD void mul(E& r, const E& x, const E& y) {
     Fp<M> a, b, t, aA, bB, sx, sy;
@@ -91,6 +93,7 @@ template <int M, unsigned NR>
 struct FieldFp3 {
   using E = Fp3E<M>;
   static constexpr int DEG = 3;
+  static constexpr int LANES = 1;
   static constexpr int MOD = M;
   static HD void mul(E& r, const E& x, const E& y) {
     Fp<M> a, b, t, aA, bB, cC, t_bc, t_ab, t_ac;
@@ -149,7 +152,11 @@ struct FieldFp3 {
 // ------------------------------------------------------------------------------------------
 HD uint32_t pair_swap_u32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(MNT753_PAIR_DPP)
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+#else
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u) ^ 1u) << 2), (int)v);
+#endif
 #else
   return v;   // host builds only need this to compile
 #endif
@@ -165,6 +172,7 @@ template <int M, unsigned NR>
 struct FieldFp2S {
   using E = Fp<M>;
   static constexpr int DEG = 2;      // components per element in memory (same layout as FieldFp2)
+  static constexpr int LANES = 2;    // lanes that share one element
   static constexpr int MOD = M;
   static HD void mul(E& r, const E& x, const E& y) {
     E xo, b1, b2;
@@ -193,6 +201,68 @@ struct FieldFp2S {
   static HD void one(E& r) {
     fp_one(r);
     if (lane_is_odd()) fp_zero(r);
+  }
+};
+
+// Lane-split Fq3: THREE adjacent lanes (3g, 3g+1, 3g+2 of a wave; lane 63 idles) hold one element, component =
+// lane % 3.  Component k of a product is   x_k*y_0 + f1*x_{k+1}*y_2 + f2*x_{k+2}*y_1   (indices mod 3; f1 = NR unless
+// k = 2, f2 = NR only for k = 0): ONE fp_mul3 per lane.  Operands of the other two lanes are fetched with
+// ds_bpermute (the wave's LDS crossbar; no LDS memory is used).
+HD uint32_t lane_fetch_u32(uint32_t v, int src_lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+#else
+  (void)src_lane;
+  return v;
+#endif
+}
+HD int wave_lane() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)(threadIdx.x & 63u);
+#else
+  return 0;
+#endif
+}
+template <int M, unsigned NR>
+struct FieldFp3S {
+  using E = Fp<M>;
+  static constexpr int DEG = 3;
+  static constexpr int LANES = 3;
+  static constexpr int MOD = M;
+  static HD void mul(E& r, const E& x, const E& y) {
+    const int lane = wave_lane(), k = lane % 3, g = lane - k;
+    const int l1 = g + (k + 1) % 3, l2 = g + (k + 2) % 3;
+    E x1, x2, y0, y1, y2;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      x1.l[i] = lane_fetch_u32(x.l[i], l1);
+      x2.l[i] = lane_fetch_u32(x.l[i], l2);
+      y0.l[i] = lane_fetch_u32(y.l[i], g);
+      y1.l[i] = lane_fetch_u32(y.l[i], g + 1);
+      y2.l[i] = lane_fetch_u32(y.l[i], g + 2);
+    }
+    E n1, n2;
+    fp_mul_small(n1, x1, NR);
+    fp_mul_small(n2, x2, NR);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      x1.l[i] = (k != 2) ? n1.l[i] : x1.l[i];
+      x2.l[i] = (k == 0) ? n2.l[i] : x2.l[i];
+    }
+    fp_mul3(r, x, y0, x1, y2, x2, y1);
+  }
+  static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
+  static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
+  static HD void neg(E& r, const E& a) { fp_neg(r, a); }
+  static HD bool is_zero(const E& a) {
+    const int lane = wave_lane(), g = lane - lane % 3;
+    const uint32_t z = fp_is_zero(a) ? 1u : 0u;
+    return (lane_fetch_u32(z, g) & lane_fetch_u32(z, g + 1) & lane_fetch_u32(z, g + 2)) != 0;
+  }
+  static HD void zero(E& r) { fp_zero(r); }
+  static HD void one(E& r) {
+    fp_one(r);
+    if (wave_lane() % 3 != 0) fp_zero(r);
   }
 };
 
@@ -237,9 +307,23 @@ struct Mnt4G2S {
   static HD void mul_by_a(F::E& r, const F::E& x) { fp_mul_small(r, x, 26u); }   // (26 c0, 26 c1), component-wise
   static HD void coeff_a(F::E& r) { F::E o; F::one(o); mul_by_a(r, o); }
 };
+// lane-split counterpart of Mnt6G2 (three lanes per point): mul_by_a(c0,c1,c2) = (121 c1, 121 c2, 11 c0)
+struct Mnt6G2S {
+  using F = FieldFp3S<MOD_A, 11u>;
+  static constexpr int FR = MOD_B;
+  static HD void mul_by_a(F::E& r, const F::E& x) {
+    const int lane = wave_lane(), k = lane % 3, g = lane - k;
+    F::E nx;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) nx.l[i] = lane_fetch_u32(x.l[i], g + (k + 1) % 3);
+    fp_mul_small(r, nx, k == 2 ? 11u : 121u);
+  }
+  static HD void coeff_a(F::E& r) { F::E o; F::one(o); mul_by_a(r, o); }
+};
 // C -> its lane-split configuration (void: none, the group runs one lane per point)
 template <class C> struct SplitOf { using type = void; };
 template <> struct SplitOf<Mnt4G2> { using type = Mnt4G2S; };
+template <> struct SplitOf<Mnt6G2> { using type = Mnt6G2S; };
 
 template <class C>
 struct Proj {

@@ -93,16 +93,6 @@ bool use_split_acc() {
   if (const char* e = getenv("MNT753_MSM_ACC")) return strcmp(e, "vm") != 0 && strcmp(e, "uniform") != 0;
   return true;
 }
-template <class C>
-void launch_split_acc(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b) {
-  using CS = typename SplitOf<C>::type;
-  if constexpr (!std::is_void<CS>::value) {
-    const unsigned threads = p.n_lanes * (unsigned)CS::F::DEG;
-    hipLaunchKernelGGL((k_bucket_accumulate_s<CS>), dim3((threads + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
-                       p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
-  }
-}
-
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
                   b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage, b->d_raw_buckets, b->d_raw_edges, b->d_bucket_state};
@@ -208,6 +198,76 @@ void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
   acc.to_wire(out);
 }
 
+// The stages that run point arithmetic.  V = the configuration the point-operation VM is instantiated with (C itself,
+// or its lane-split counterpart); kernels that only move points are layout-agnostic and use C.
+template <class V, class C>
+int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, uint32_t** result) {
+  // development: MNT753_SPLIT_MASK selects which kernels run lane-split (bit 0 accumulate, 1 edge sum, 2 bucket reduce, 3 tree)
+  unsigned mask = 0xf;
+  if (const char* e = getenv("MNT753_SPLIT_MASK")) mask = (unsigned)atoi(e);
+  // accumulate kernel: the lane-divergent projective VM (default: measured faster) or the wave-uniform XYZZ
+  // programs of vm_uniform.cuh (MNT753_MSM_ACC=uniform)
+  bool uniform_acc = false;
+  if (const char* e = getenv("MNT753_MSM_ACC")) uniform_acc = strcmp(e, "uniform") == 0;
+  if (uniform_acc) {
+    HIP_TRY(hipMemsetAsync(b->d_bucket_state, 0, (size_t)p.n_buckets, st));
+    hipLaunchKernelGGL((k_bucket_accumulate_u<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
+                       p.n_buckets, b->d_raw_buckets, b->d_raw_edges, b->d_edge_bucket, b->d_bucket_state, p.T, p.n_lanes);
+    hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, b->d_raw_buckets, b->d_buckets,
+                       b->d_bucket_state, (const uint32_t*)nullptr, p.n_buckets);
+    hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_raw_edges, b->d_edges,
+                       (const uint8_t*)nullptr, b->d_edge_bucket, 2 * p.n_lanes);
+  } else {
+    if (mask & 1u)
+      hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
+                         p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
+    else
+      hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3(blocks_for<typename C::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
+                         p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
+  }
+  HIP_TRY(hipEventRecord(b->ev[2], st));
+  {
+    const uint32_t n_slots = 2 * p.n_lanes;
+    const unsigned gs = (n_slots + 255) / 256, gv = blocks_for<typename V::F>(n_slots);
+    HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));
+    uint32_t level = 0;
+    for (uint32_t dist = 1; dist < n_slots; dist <<= 1, ++level) {
+      if (mask & 2u)
+        hipLaunchKernelGGL((k_edge_level_sum<V>), dim3(gv), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
+                           b->d_edge_flags, level);
+      else
+        hipLaunchKernelGGL((k_edge_level_sum<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
+                           b->d_edge_flags, level);
+      hipLaunchKernelGGL((k_edge_level_copy<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
+                         b->d_edge_flags, level);
+    }
+    hipLaunchKernelGGL((k_edge_finish<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_buckets, n_slots);
+  }
+  if (mask & 4u)
+    hipLaunchKernelGGL((k_bucket_reduce<V>), dim3(blocks_for<typename V::F>(p.n_chunks)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,
+                       b->d_tmp, p.nb, p.L, p.n_chunks, p.c - 1);
+  else
+    hipLaunchKernelGGL((k_bucket_reduce<C>), dim3(blocks_for<typename C::F>(p.n_chunks)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,
+                       b->d_tmp, p.nb, p.L, p.n_chunks, p.c - 1);
+  // tree: [W][n_in] -> [W][1]
+  const uint32_t NS = p.n_sets;   // bucket sets = points that survive the reduction
+  uint32_t n_in = p.nb / p.L;
+  uint32_t* cur = b->d_part_a;
+  uint32_t* nxt = b->d_part_b;
+  const uint32_t R = 2;   // log-depth: every level is one group addition deep
+  while (n_in > 1) {
+    uint32_t n_out = (n_in + R - 1) / R;
+    if (mask & 8u)
+      hipLaunchKernelGGL((k_tree_sum<V>), dim3(blocks_for<typename V::F>((uint64_t)NS * n_out)), dim3(256), 0, st, cur, nxt, NS, n_in, n_out, R);
+    else
+      hipLaunchKernelGGL((k_tree_sum<C>), dim3(blocks_for<typename C::F>((uint64_t)NS * n_out)), dim3(256), 0, st, cur, nxt, NS, n_in, n_out, R);
+    std::swap(cur, nxt);
+    n_in = n_out;
+  }
+  *result = cur;
+  return 0;
+}
+
 // Enqueue one MSM on stream `st` (no host synchronisation); msm_finish_t collects the result.
 template <class C, class HC>
 int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n, hipStream_t st) {
@@ -242,52 +302,17 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_cursor, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
                      p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u);
   HIP_TRY(hipEventRecord(b->ev[1], st));
-  // accumulate kernel: the lane-divergent projective VM (default: measured faster) or the wave-uniform XYZZ
-  // programs of vm_uniform.cuh (MNT753_MSM_ACC=uniform)
-  bool uniform_acc = false;
-  if (const char* e = getenv("MNT753_MSM_ACC")) uniform_acc = strcmp(e, "uniform") == 0;
-  if (uniform_acc) {
-    HIP_TRY(hipMemsetAsync(b->d_bucket_state, 0, (size_t)p.n_buckets, st));
-    hipLaunchKernelGGL((k_bucket_accumulate_u<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
-                       p.n_buckets, b->d_raw_buckets, b->d_raw_edges, b->d_edge_bucket, b->d_bucket_state, p.T, p.n_lanes);
-    hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, b->d_raw_buckets, b->d_buckets,
-                       b->d_bucket_state, (const uint32_t*)nullptr, p.n_buckets);
-    hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_raw_edges, b->d_edges,
-                       (const uint8_t*)nullptr, b->d_edge_bucket, 2 * p.n_lanes);
-  } else if (use_split_acc<C>()) {
-    launch_split_acc<C>(p, st, d_aff, b);
-  } else {
-    hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
-                       p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
-  }
-  HIP_TRY(hipEventRecord(b->ev[2], st));
+  // point stages: with the lane-split configuration of the group (Fq2: two lanes per point, Fq3: three) when it has
+  // one, otherwise one lane per point.  MNT753_MSM_ACC=vm forces one lane, =uniform the wave-uniform XYZZ accumulate.
+  uint32_t* cur = nullptr;
   {
-    const uint32_t n_slots = 2 * p.n_lanes;
-    const unsigned gs = (n_slots + 255) / 256;
-    HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));
-    uint32_t level = 0;
-    for (uint32_t dist = 1; dist < n_slots; dist <<= 1, ++level) {
-      hipLaunchKernelGGL((k_edge_level_sum<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
-                         b->d_edge_flags, level);
-      hipLaunchKernelGGL((k_edge_level_copy<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
-                         b->d_edge_flags, level);
-    }
-    hipLaunchKernelGGL((k_edge_finish<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_buckets, n_slots);
+    int rc;
+    using CS = typename SplitOf<C>::type;
+    if constexpr (!std::is_void<CS>::value) rc = use_split_acc<C>() ? point_stages<CS, C>(p, st, d_aff, b, &cur) : point_stages<C, C>(p, st, d_aff, b, &cur);
+    else rc = point_stages<C, C>(p, st, d_aff, b, &cur);
+    if (rc) return rc;
   }
-  hipLaunchKernelGGL((k_bucket_reduce<C>), dim3((p.n_chunks + 255) / 256), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,
-                     b->d_tmp, p.nb, p.L, p.n_chunks, p.c - 1);
-  // tree: [W][n_in] -> [W][1]
-  const uint32_t NS = p.n_sets;   // bucket sets = points that survive the reduction
-  uint32_t n_in = p.nb / p.L;
-  uint32_t* cur = b->d_part_a;
-  uint32_t* nxt = b->d_part_b;
-  const uint32_t R = 2;   // log-depth: every level is one group addition deep
-  while (n_in > 1) {
-    uint32_t n_out = (n_in + R - 1) / R;
-    hipLaunchKernelGGL((k_tree_sum<C>), dim3((NS * n_out + 255) / 256), dim3(256), 0, st, cur, nxt, NS, n_in, n_out, R);
-    std::swap(cur, nxt);
-    n_in = n_out;
-  }
+  const uint32_t NS = p.n_sets;
   hipLaunchKernelGGL((k_points_to_wire<C>), dim3((NS + 63) / 64), dim3(64), 0, st, cur, b->d_wire_out, NS);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[3], st));

@@ -64,15 +64,51 @@ __device__ __forceinline__ void fp_store(uint32_t* p, const Fp<M>& a) {
     q[i] = v;
   }
 }
+// ---- thread -> (logical lane, component) ------------------------------------------------------------------
+// One-lane fields: thread = logical lane.  Lane-split fields (FieldFp2S / FieldFp3S, curve753.cuh): LANES adjacent
+// threads form one logical lane and each of them loads / stores only its own component of every element, so the
+// memory layout is identical and split and one-lane kernels can be mixed freely in one pipeline.
+//   LANES = 2: threads (2j, 2j+1);   LANES = 3: lanes (3g, 3g+1, 3g+2) of a wave, lane 63 idles (21 triples per wave).
+// All point kernels are launched with 256-thread blocks.
+template <class F>
+__device__ __forceinline__ uint32_t logical_lane() {
+  if constexpr (F::LANES == 1) return blockIdx.x * blockDim.x + threadIdx.x;
+  else if constexpr (F::LANES == 2) return (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  else {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane == 63u) return 0xffffffffu;
+    return (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 21u + lane / 3u;
+  }
+}
+template <class F>
+__device__ __forceinline__ uint32_t lane_comp() {
+  if constexpr (F::LANES == 1) return 0u;
+  else if constexpr (F::LANES == 2) return threadIdx.x & 1u;
+  else return (threadIdx.x & 63u) % 3u;
+}
+// 256-thread blocks needed for n logical lanes (host side)
+template <class F>
+constexpr unsigned blocks_for(uint64_t n) {
+  return F::LANES == 3 ? (unsigned)((n + 83) / 84) : (unsigned)((n * F::LANES + 255) / 256);
+}
+
 template <class F>
 __device__ __forceinline__ void e_load(typename F::E& r, const uint32_t* p) {
+  if constexpr (F::LANES == 1) {
 #pragma unroll
-  for (int k = 0; k < F::DEG; ++k) fp_load(F::comp(r, k), p + k * FPS_WORDS);
+    for (int k = 0; k < F::DEG; ++k) fp_load(F::comp(r, k), p + k * FPS_WORDS);
+  } else {
+    fp_load(r, p + lane_comp<F>() * FPS_WORDS);
+  }
 }
 template <class F>
 __device__ __forceinline__ void e_store(uint32_t* p, const typename F::E& a) {
+  if constexpr (F::LANES == 1) {
 #pragma unroll
-  for (int k = 0; k < F::DEG; ++k) fp_store(p + k * FPS_WORDS, F::comp(a, k));
+    for (int k = 0; k < F::DEG; ++k) fp_store(p + k * FPS_WORDS, F::comp(a, k));
+  } else {
+    fp_store(p + lane_comp<F>() * FPS_WORDS, a);
+  }
 }
 template <class C>
 constexpr int aff_words() { return 2 * C::F::DEG * FPS_WORDS; }
@@ -326,7 +362,7 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
                                                              uint32_t* __restrict__ buckets, uint32_t* __restrict__ edges,
                                                              uint32_t* __restrict__ edge_bucket, uint32_t T, uint32_t n_lanes) {
   using F = typename C::F;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = logical_lane<typename C::F>();
   if (t >= n_lanes) return;
   const uint32_t total = offsets[n_buckets];
   uint64_t e0 = (uint64_t)t * T;
@@ -389,89 +425,6 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
     edge_bucket[2 * t + 1] = b;
   } else {
     proj_store<C>(edges + (size_t)(2 * t + 1) * proj_words<C>(), acc);
-    edge_bucket[2 * t + 1] = b;
-  }
-}
-
-// ---- bucket accumulation, lane-split version (two lanes per point, FieldFp2S) -------------------------------
-// Same schedule and same outputs as k_bucket_accumulate<C> -- logical lane t = thread / 2 owns sorted entries
-// [t*T, (t+1)*T) -- but thread parity k selects the Fq2 component this lane loads, computes and stores.  Memory layout
-// of points is unchanged, so every other kernel of the pipeline is shared with the one-lane path.
-template <class CS>
-__device__ __forceinline__ void proj_store_split(uint32_t* p, const Proj<CS>& P, uint32_t k) {
-  constexpr int D = CS::F::DEG;
-  fp_store(p + k * FPS_WORDS, P.X);
-  fp_store(p + (D + k) * FPS_WORDS, P.Y);
-  fp_store(p + (2 * D + k) * FPS_WORDS, P.Z);
-}
-template <class CS>
-__global__ void __launch_bounds__(256, 1) k_bucket_accumulate_s(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                                const uint32_t* __restrict__ offsets, uint32_t n_buckets,
-                                                                uint32_t* __restrict__ buckets, uint32_t* __restrict__ edges,
-                                                                uint32_t* __restrict__ edge_bucket, uint32_t T, uint32_t n_lanes) {
-  using F = typename CS::F;
-  constexpr int D = F::DEG;
-  constexpr int AW = 2 * D * FPS_WORDS, PW = 3 * D * FPS_WORDS;
-  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t t = gt / D, k = gt % D;
-  if (t >= n_lanes) return;
-  const uint32_t total = offsets[n_buckets];
-  uint64_t e0 = (uint64_t)t * T;
-  if (e0 >= total) {
-    edge_bucket[2 * t] = EDGE_NONE;
-    edge_bucket[2 * t + 1] = EDGE_NONE;
-    return;
-  }
-  uint32_t e = (uint32_t)e0;
-  uint32_t end = (e0 + T < total) ? (uint32_t)(e0 + T) : total;
-  uint32_t lo = 0, hi = n_buckets;
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (offsets[mid + 1] > e) hi = mid; else lo = mid + 1;
-  }
-  uint32_t b = lo;
-  uint32_t next = offsets[b + 1];
-  bool first_run = true;
-  bool acc_zero = true;
-  Proj<CS> acc, Q;
-  pt_set_zero(acc);
-  F::one(Q.Z);
-  for (; e < end; ++e) {
-    if (e == next) {
-      if (first_run) {
-        proj_store_split<CS>(edges + (size_t)(2 * t) * PW, acc, k);
-        edge_bucket[2 * t] = b;
-        first_run = false;
-      } else {
-        proj_store_split<CS>(buckets + (size_t)b * PW, acc, k);
-      }
-      acc_zero = true;
-      do { ++b; next = offsets[b + 1]; } while (next == e);
-    }
-    uint32_t s = sorted[e];
-    const uint32_t* src = bases + (size_t)(s & 0x7fffffffu) * AW;
-    fp_load(Q.X, src + k * FPS_WORDS);
-    fp_load(Q.Y, src + (D + k) * FPS_WORDS);
-    if (s & 0x80000000u) F::neg(Q.Y, Q.Y);
-    int pc = PC_MADD;
-    if (acc_zero) {
-      acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z);
-      acc_zero = false;
-      pc = PC_END;
-    } else if (pt_is_zero(acc)) {
-      acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z);
-      pc = PC_END;
-    }
-    pt_vm<CS, false>(acc, Q, pc);
-  }
-  if (first_run) {
-    proj_store_split<CS>(edges + (size_t)(2 * t) * PW, acc, k);
-    edge_bucket[2 * t] = b;
-    pt_set_zero(acc);
-    proj_store_split<CS>(edges + (size_t)(2 * t + 1) * PW, acc, k);
-    edge_bucket[2 * t + 1] = b;
-  } else {
-    proj_store_split<CS>(edges + (size_t)(2 * t + 1) * PW, acc, k);
     edge_bucket[2 * t + 1] = b;
   }
 }
@@ -616,7 +569,7 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_edge_level_sum(const uin
                                                           uint32_t* __restrict__ tmp, uint32_t n_slots, uint32_t dist,
                                                           uint32_t* __restrict__ flags, uint32_t level) {
   if (level > 0 && flags[level - 1] == 0) return;   // no run longer than dist/1: nothing left to do
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = logical_lane<typename C::F>();
   if (j >= n_slots || j + dist >= n_slots) return;
   const uint32_t b = edge_bucket[j];
   if (b == EDGE_NONE || edge_bucket[j + dist] != b) return;
@@ -667,7 +620,7 @@ template <class C>
 __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_reduce(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ tmp, uint32_t nb,
                                                          uint32_t L, uint32_t n_chunks_total, int kbits) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = logical_lane<typename C::F>();
   if (t >= n_chunks_total) return;
   constexpr int PW = proj_words<C>();
   const uint32_t chunks_per_window = nb / L;
@@ -727,7 +680,7 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_reduce(const uint
 template <class C>
 __global__ void __launch_bounds__(256, vm_waves<C>()) k_tree_sum(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t W,
                                                     uint32_t n_in, uint32_t n_out, uint32_t R) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = logical_lane<typename C::F>();
   if (t >= W * n_out) return;
   const uint32_t w = t / n_out, o = t % n_out;
   const uint32_t first = o * R;
