@@ -182,6 +182,14 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
     b->pre_c = pc;
     b->pre_W = pW;
   }
+  // Workspace and events of a full-size MSM over this set are allocated here, at parameter-load time, so that the
+  // first mnt753_msm* call on the set does not start with ~20 hipMallocs.
+  {
+    MsmPlan p = make_plan(n, b->pre_c);
+    if (int rc = ensure_ws<C>(b, n, p)) return rc;
+    for (int i = 0; i < 5; ++i)
+      if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
+  }
   return 0;
 }
 
