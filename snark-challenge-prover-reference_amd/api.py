@@ -207,6 +207,13 @@ class DeviceBuffer:
         _check(lib().mnt753_copy_h2d(b.ptr, C.c_void_p(a.ctypes.data), a.nbytes), "mnt753_copy_h2d")
         return b
 
+    @classmethod
+    def from_file(cls, path, offset, nbytes):
+        """Stream nbytes of a file (from byte offset) into new device memory (mnt753_load_file_to_device)."""
+        b = cls(nbytes)
+        _check(lib().mnt753_load_file_to_device(str(path).encode(), int(offset), int(nbytes), b.ptr), "mnt753_load_file_to_device")
+        return b
+
     def to_numpy(self, dtype=np.uint64):
         out = np.zeros(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
         _check(lib().mnt753_copy_d2h(C.c_void_p(out.ctypes.data), self.ptr, self.nbytes), "mnt753_copy_d2h")

@@ -11,6 +11,7 @@
 // inlined instance of the 1458-MAD multiplier (~14 KB of code): the hot loop stays inside the
 // 64 KB instruction cache instead of streaming ~160 KB of straight-line code per addition.
 #pragma once
+#include <type_traits>
 #include "fp753.cuh"
 
 namespace mnt753 {
@@ -24,7 +25,9 @@ struct FieldFp {
   static constexpr int DEG = 1;
   static constexpr int LANES = 1;
   static constexpr int MOD = M;
+  static constexpr bool HAS_SQR = true;
   static HD void mul(E& r, const E& a, const E& b) { fp_mul(r, a, b); }
+  static HD void sqr(E& r, const E& a) { fp_sqr(r, a); }
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
   static HD void neg(E& r, const E& a) { fp_neg(r, a); }
@@ -325,6 +328,9 @@ template <class C> struct SplitOf { using type = void; };
 template <> struct SplitOf<Mnt4G2> { using type = Mnt4G2S; };
 template <> struct SplitOf<Mnt6G2> { using type = Mnt6G2S; };
 
+template <class F, class = void> struct has_sqr : std::false_type {};
+template <class F> struct has_sqr<F, std::enable_if_t<F::HAS_SQR>> : std::true_type {};
+
 template <class C>
 struct Proj {
   typename C::F::E X, Y, Z;
@@ -394,7 +400,14 @@ HD void pt_vm(Proj<C>& P, const Proj<C>& Q, int pc) {
       case 36: if (WITH_ADD) { a = P.Z; b = Q.Z; } break;
       default: break;
     }
-    F::mul(r, a, b);
+    if constexpr (has_sqr<F>::value) {
+      // squaring steps (u^2, v^2 of an addition; six steps of a doubling) take the cheaper squaring; in the accumulate
+      // kernel all lanes of a wave sit at the same step, so the two multipliers are not run back to back
+      const bool sq = pc == 2 || pc == 3 || pc == 16 || pc == 17 || pc == 19 || pc == 22 || pc == 23 || pc == 24;
+      if (sq) F::sqr(r, a); else F::mul(r, a, b);
+    } else {
+      F::mul(r, a, b);
+    }
     switch (pc) {
       case 0: F::sub(v, r, P.X); pc = 1; break;
       case 1:

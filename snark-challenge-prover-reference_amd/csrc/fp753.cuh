@@ -68,6 +68,42 @@ HD void fp_mul(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
   r.l[NL - 1] = (uint32_t)acc;
 }
 
+// r = a*a*2^-756 mod p.  Cross products a_i*a_j (i < j) are taken once against the pre-doubled operand 2a (limbs < 2^29),
+// the diagonal once: 351 + 27 product MADs instead of 729; the reduction half is unchanged (729).  1107 MADs vs 1458.
+template <int M>
+HD void fp_sqr(Fp<M>& r, const Fp<M>& a) {
+  uint64_t acc = 0, acc2 = 0;
+  uint32_t m[NL], d[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) d[i] = a.l[i] << 1;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)a.l[i] * d[k - i];
+    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += acc2;
+    acc2 = 0;
+    m[k] = ((uint32_t)acc * FPC[M].inv) & LMASK;
+    acc += (uint64_t)m[k] * FPC[M].p[0];
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; 2 * i < k; ++i) acc += (uint64_t)a.l[i] * d[k - i];
+    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += acc2;
+    acc2 = 0;
+    r.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+}
+
 // r = (a1*b1 + a2*b2) * 2^-756 mod p with ONE Montgomery reduction: 2*729 + 729 = 2187 multiply-adds instead of the
 // 2916 of two separate products.  All four inputs in [0, 2p): the sum is < 8p^2, so r < p(8p/R' + 1) < 2p because
 // 8p < 0.89 R' for both moduli (p ~ 1.77 * 2^752).  A column holds at most 54 + 27 products < 2^57 and one carry, well

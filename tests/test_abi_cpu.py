@@ -52,6 +52,7 @@ def test_no_cpu_fallback(pkg):
     assert L.mnt753_bases_create(0, 1, ctypes.c_void_p(aff.ctypes.data), 0, 1, ctypes.byref(h)) == -2
     assert L.mnt753_domain_create(0, 8, ctypes.byref(h)) == -2
     assert L.mnt753_vec_muleq(0, ctypes.c_void_p(8), ctypes.c_void_p(8), 1, None) == -2
+    assert L.mnt753_load_file_to_device(b"/dev/null", 0, 0, None) == -2
     with pytest.raises(pkg.Mnt753Error):
         pkg.init(0)
 
@@ -106,3 +107,15 @@ def test_synthetic_inputs(pkg, curve, group):
     z = np.zeros_like(sc[:1040]); z[sel] = sc[sel]
     exp = pkg.point_to_affine(curve, group, pkg.synth_expected_msm(curve, group, 99, z))
     assert np.array_equal(O.msm(curve, group, a[sel], sc[sel]), exp)
+
+
+def test_device_field_arithmetic_compiled_for_the_host(tmp_path):
+    """fp753.cuh is __host__ __device__: the fused multipliers of the lane-split extension fields (fp_mul2, fp_mul3) and
+    the dedicated squaring (fp_sqr) must agree with compositions of the plain Montgomery product fp_mul -- which the
+    oracle-pinned GPU parity tests cover -- and keep their results in [0, 2p).  2000 random cases per modulus."""
+    import subprocess
+    exe = tmp_path / "host_fp_check"
+    src = os.path.join(ROOT, "tools", "host_fp_check.cpp")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), src], check=True, timeout=600)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr

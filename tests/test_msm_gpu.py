@@ -175,3 +175,40 @@ def test_large_g2_both_curves(gpu):
         pts = gpu.synth_points(curve, 2, 61, n); sc = gpu.synth_scalars(curve, 62, n)
         got = gpu_msm_affine(gpu, curve, 2, pts, sc)
         assert np.array_equal(got, gpu.point_to_affine(curve, 2, gpu.synth_expected_msm(curve, 2, 61, sc)))
+
+
+@pytest.mark.parametrize("curve,n", [(0, 1 << 16), (1, 1 << 14), (0, 300), (1, 300)])
+def test_g2_lane_split_matches_one_lane_kernels(gpu, curve, n, monkeypatch):
+    """G2 point kernels run with two (Fq2) / three (Fq3) lanes per point by default; MNT753_MSM_ACC=vm selects the
+    one-lane-per-point kernels.  Same base set, same scalars (with duplicates, an identity base, zero / one scalars and
+    a P + (-P) pair so the doubling and identity paths of the split VM are exercised): identical projective words are
+    not required, identical affine results are, and both must equal the known-discrete-log expectation."""
+    pts = gpu.synth_points(curve, 2, 81, n); sc = gpu.synth_scalars(curve, 82, n)
+    pts[7] = pts[6]; sc[7] = sc[6]              # equal operands -> doubling inside a bucket
+    sc[3] = 0; sc[4] = gpu.api.mont_one(curve)
+    bs = gpu.BaseSet(curve, 2, pts)
+    try:
+        monkeypatch.delenv("MNT753_MSM_ACC", raising=False)
+        split = gpu.point_to_affine(curve, 2, bs.msm(sc))
+        monkeypatch.setenv("MNT753_MSM_ACC", "vm")
+        one_lane = gpu.point_to_affine(curve, 2, bs.msm(sc))
+    finally:
+        bs.close()
+    assert np.array_equal(split, one_lane)
+    if n <= 300:
+        assert np.array_equal(split, O.msm(curve, 2, pts, sc))
+
+
+def test_g2_lane_split_repeatable_at_sizes_that_faulted_with_dpp(gpu):
+    """Regression: with a DPP quad_perm pair exchange k_bucket_reduce<Mnt4G2S> faulted / miscomputed at 2^16..2^19
+    (never at 2^10..2^13); the exchange is ds_bpermute now.  Two runs per size must agree with the expectation."""
+    for logn in (16, 17):
+        n = 1 << logn
+        pts = gpu.synth_points(0, 2, 91, n); sc = gpu.synth_scalars(0, 92, n)
+        exp = gpu.point_to_affine(0, 2, gpu.synth_expected_msm(0, 2, 91, sc))
+        bs = gpu.BaseSet(0, 2, pts)
+        try:
+            for _ in range(2):
+                assert np.array_equal(gpu.point_to_affine(0, 2, bs.msm(sc)), exp)
+        finally:
+            bs.close()

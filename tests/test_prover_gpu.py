@@ -5,6 +5,7 @@ import filecmp
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import golden_io as G
@@ -68,3 +69,22 @@ def test_cli_errors(gpu, tmp_path):
     assert r.returncode == 1 and "cannot open" in r.stderr
     r = subprocess.run([EXE, "BN128", "compute", "a", "b", "c"], capture_output=True, text=True)
     assert r.returncode == 2
+
+
+def test_load_file_to_device_roundtrip(gpu, tmp_path):
+    """mnt753_load_file_to_device (the input loader of B::read_input): arbitrary offset, a size that is not a multiple
+    of the 16 MiB staging chunk, an empty region, and the error paths (missing file, short file)."""
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 1 << 63, size=(40 << 20) // 8 + 3, dtype=np.uint64)   # 40 MiB + 24 B: three staging chunks
+    path = tmp_path / "blob.bin"
+    data.tofile(path)
+    buf = gpu.DeviceBuffer.from_file(path, 0, data.nbytes)
+    assert np.array_equal(buf.to_numpy(), data)
+    part = gpu.DeviceBuffer.from_file(path, 8 * 1000, 8 * 123457)
+    assert np.array_equal(part.to_numpy(), data[1000:1000 + 123457])
+    gpu.DeviceBuffer.from_file(path, 16, 0).close()
+    with pytest.raises(gpu.api.Mnt753Error):
+        gpu.DeviceBuffer.from_file(tmp_path / "missing.bin", 0, 64)
+    with pytest.raises(gpu.api.Mnt753Error):
+        gpu.DeviceBuffer.from_file(path, data.nbytes - 8, 64)
+    buf.close(); part.close()

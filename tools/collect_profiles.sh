@@ -1,0 +1,48 @@
+#!/bin/sh
+# GPU box: the evidence bundle of a round -> gpurun_out/prof/ (copy what is to be judged into profiles/rNN/).
+#   bench line, rocprofv3 kernel stats of the bench command, the two PMC passes (separate runs, as the microarch
+#   guide prescribes), kernel stats of a G2 MSM, and the full-size proves.  usage: tools/collect_profiles.sh
+cd "$(dirname "$0")/.."
+R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
+python bench.py > $O/bench_line.json 2> $O/bench_stderr.log
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+CURVE=0 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2 -o g2 -- python3 $R/tools/dev_msm_big.py 20 3 > $O/g2_msm_2p20.log 2>/dev/null
+CURVE=1 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2m6 -o g2 -- python3 $R/tools/dev_msm_big.py 15 3 > $O/g2_mnt6_msm_2p15.log 2>/dev/null
+cd $R
+sh tools/full_prove.sh MNT4753 20 skip-cpu > $O/full_prove_MNT4753_2p20.log 2>&1
+sh tools/full_prove.sh MNT6753 15 skip-cpu > $O/full_prove_MNT6753_2p15.log 2>&1
+# keep the summaries, drop the bulky databases
+python3 - <<'PY'
+import sqlite3, glob, os, csv, collections
+O = os.path.join(os.getcwd(), "gpurun_out", "prof")
+def tables(cur): return [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+for db in glob.glob(O + "/*/*_results.db"):
+    con = sqlite3.connect(db); cur = con.cursor(); t = tables(cur)
+    kd = [x for x in t if "kernel_dispatch" in x][0]; ks = [x for x in t if "kernel_symbol" in x][0]
+    tag = os.path.basename(os.path.dirname(db))
+    rows = list(cur.execute(f"select s.display_name, d.end - d.start, d.id from {kd} d join {ks} s on d.kernel_id = s.id"))
+    agg = collections.defaultdict(list)
+    for n, dt, _ in rows: agg[n].append(dt)
+    total = sum(sum(v) for v in agg.values()) or 1
+    with open(f"{O}/{tag}_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([n, len(v), sum(v), sum(v) / len(v), round(100 * sum(v) / total, 2), min(v), max(v)])
+    pm = [x for x in t if "pmc_event" in x]; pi = [x for x in t if "info_pmc" in x]
+    if pm and pi:
+        q = f"select s.display_name, p.symbol, e.value from {pm[0]} e join {pi[0]} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id"
+        try:
+            pa = collections.defaultdict(list)
+            for n, sym, val in cur.execute(q): pa[(n, sym)].append(val)
+            if pa:
+                with open(f"{O}/{tag}_pmc.csv", "w", newline="") as f:
+                    w = csv.writer(f); w.writerow(["kernel", "counter", "launches", "avg_value"])
+                    for (n, sym), v in sorted(pa.items(), key=lambda kv: -sum(kv[1])): w.writerow([n, sym, len(v), sum(v) / len(v)])
+        except Exception as ex:
+            open(f"{O}/{tag}_pmc_error.txt", "w").write(repr(ex))
+    con.close(); os.remove(db)
+PY
+ls -la $O
