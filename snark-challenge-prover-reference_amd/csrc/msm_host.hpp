@@ -50,7 +50,9 @@ int pick_precomp_bits(size_t n) {
   return best;
 }
 
-MsmPlan make_plan(size_t n, int pre_c) {
+// lanes_per_point: threads that share one point in the point kernels (1, or 2 / 3 with the lane-split G2 fields); the
+// machine holds 65536 threads at one wave per SIMD, i.e. 65536 / lanes_per_point points at a time
+MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   MsmPlan p;
   p.pre = pre_c > 0 && g_window_bits_override == 0;
   p.c = p.pre ? pre_c : pick_window_bits(n);
@@ -62,7 +64,8 @@ MsmPlan make_plan(size_t n, int pre_c) {
   const uint64_t entries = (uint64_t)p.W * n;
   int rounds = 2;
   if (const char* e = getenv("MNT753_MSM_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 64) rounds = v; }
-  uint64_t lanes_target = (uint64_t)65536 * rounds;
+  const uint64_t machine = lanes_per_point == 3 ? 21504u : 65536u / (unsigned)lanes_per_point;   // 21 triples per wave
+  uint64_t lanes_target = machine * rounds;
   uint64_t T = (entries + lanes_target - 1) / lanes_target;
   if (T < 16) T = 16;
   p.T = (uint32_t)T;
@@ -70,7 +73,7 @@ MsmPlan make_plan(size_t n, int pre_c) {
   if (p.n_lanes == 0) p.n_lanes = 1;
   // reduce chunk: ~one round of lanes
   uint32_t L = 1;
-  while ((uint64_t)p.n_buckets / L > 65536 && L < p.nb) L <<= 1;
+  while ((uint64_t)p.n_buckets / L > machine && L < p.nb) L <<= 1;
   if (const char* e = getenv("MNT753_MSM_L")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v <= p.nb && (v & (v - 1)) == 0) L = v; }
   p.L = L;
   p.n_chunks = p.n_buckets / L;
@@ -92,6 +95,13 @@ bool use_split_acc() {
   if (std::is_void<typename SplitOf<C>::type>::value) return false;
   if (const char* e = getenv("MNT753_MSM_ACC")) return strcmp(e, "vm") != 0 && strcmp(e, "uniform") != 0;
   return true;
+}
+// threads per point in the point kernels of group C under the current settings
+template <class C>
+int point_lanes() {
+  using CS = typename SplitOf<C>::type;
+  if constexpr (std::is_void<CS>::value) return 1;
+  else return use_split_acc<C>() ? CS::F::LANES : 1;
 }
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
@@ -185,7 +195,7 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   // Workspace and events of a full-size MSM over this set are allocated here, at parameter-load time, so that the
   // first mnt753_msm* call on the set does not start with ~20 hipMallocs.
   {
-    MsmPlan p = make_plan(n, b->pre_c);
+    MsmPlan p = make_plan(n, b->pre_c, point_lanes<C>());
     if (int rc = ensure_ws<C>(b, n, p)) return rc;
     for (int i = 0; i < 5; ++i)
       if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
@@ -283,7 +293,7 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   if (b->pending) return set_error(MNT753_EINVAL, "msm_start: this base set already has an MSM in flight (finish it first)");
   b->pending = 1; b->pending_n = n; b->pending_stream = st;
   if (n == 0) return 0;
-  MsmPlan p = make_plan(n, b->pre_c);
+  MsmPlan p = make_plan(n, b->pre_c, point_lanes<C>());
   if (int rc = ensure_ws<C>(b, n, p)) return rc;
   g_last_plan[0] = p.c; g_last_plan[1] = p.W; g_last_plan[2] = p.pre; g_last_plan[3] = (int)p.T;
   for (int i = 0; i < 5; ++i)
