@@ -62,7 +62,7 @@ MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   p.n_buckets = p.n_sets * p.nb;
   // lanes: aim at `rounds` full rounds of the machine (256 CUs x 256 lanes, one wave per SIMD)
   const uint64_t entries = (uint64_t)p.W * n;
-  int rounds = 2;
+  int rounds = entries < ((uint64_t)1 << 23) ? 1 : 2;   // small sets: fewer lanes = fewer edge pieces to combine (measured)
   if (const char* e = getenv("MNT753_MSM_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 64) rounds = v; }
   const uint64_t machine = lanes_per_point == 3 ? 21504u : 65536u / (unsigned)lanes_per_point;   // 21 triples per wave
   uint64_t lanes_target = machine * rounds;
