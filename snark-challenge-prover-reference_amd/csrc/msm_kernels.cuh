@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include "curve753.cuh"
 #include "vm_uniform.cuh"
+#include "fp_inv.cuh"
 
 namespace mnt753 {
 
@@ -721,6 +722,7 @@ __global__ void __launch_bounds__(64) k_points_to_wire(const uint32_t* __restric
 // SAME bucket set (sum_w d_w * (2^(cw) P) = s * P), so one MSM needs W*N bucket additions into 2^(c-1) buckets,
 // ONE bucket reduction instead of W, and no Horner pass.  Built once per base set, at parameter-load time
 // (the reference's timing window opens after the parameters are loaded, libsnark/main.cpp:201-203).
+// (kept as the cross-check of fp_inv in tools/dev_inv_gpu.hip; the product path uses the divstep inversion of fp_inv.cuh)
 template <int M>
 __device__ void fp_inv_fermat(Fp<M>& r, const Fp<M>& x) {
   // x^(p-2), exponent limbs from the constants table
@@ -742,7 +744,7 @@ __device__ void fp_inv_fermat(Fp<M>& r, const Fp<M>& x) {
   r = acc;
 }
 template <int M>
-__device__ void e_inv(Fp<M>& r, const Fp<M>& a, FieldFp<M>*) { fp_inv_fermat(r, a); }
+__device__ void e_inv(Fp<M>& r, const Fp<M>& a, FieldFp<M>*) { fp_inv(r, a); }
 template <int M, unsigned NR>
 __device__ void e_inv(Fp2E<M>& r, const Fp2E<M>& x, FieldFp2<M, NR>*) {   // fp2.tcc:129-142
   Fp<M> t0, t1, t2, t3;
@@ -750,7 +752,7 @@ __device__ void e_inv(Fp2E<M>& r, const Fp2E<M>& x, FieldFp2<M, NR>*) {   // fp2
   fp_mul(t1, x.c1, x.c1);
   fp_mul_small(t1, t1, NR);
   fp_sub(t2, t0, t1);
-  fp_inv_fermat(t3, t2);
+  fp_inv(t3, t2);
   fp_mul(r.c0, x.c0, t3);
   fp_mul(t0, x.c1, t3);
   fp_neg(r.c1, t0);
@@ -765,7 +767,7 @@ __device__ void e_inv(Fp3E<M>& r, const Fp3E<M>& x, FieldFp3<M, NR>*) {   // fp3
   fp_sub(c2, t1, t4);
   fp_mul(u, x.c2, c1); fp_mul(v, x.c1, c2); fp_add(u, u, v); fp_mul_small(u, u, NR);
   fp_mul(v, x.c0, c0); fp_add(u, u, v);
-  fp_inv_fermat(t6, u);
+  fp_inv(t6, u);
   fp_mul(r.c0, t6, c0); fp_mul(r.c1, t6, c1); fp_mul(r.c2, t6, c2);
 }
 

@@ -1,7 +1,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
-#include "../snark-challenge-prover-reference_amd/csrc/fp753.cuh"   // host build: g++ -O1 -std=c++17 tools/host_fp_check.cpp
+#include "../snark-challenge-prover-reference_amd/csrc/fp_inv.cuh"   // host build: g++ -O1 -std=c++17 tools/host_fp_check.cpp
 using namespace mnt753;
 static uint64_t st = 88172645463325252ull;
 static uint64_t rnd() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; }
@@ -23,6 +23,18 @@ template <int M> int run() {
     fp_mul(t1, a, b); fp_mul(t2, c, d); fp_add(r1, t1, t2); fp_mul2(r2, a, b, c, d); if (!eq(r1, r2) || !in_range(r2)) { ++bad; if (bad < 4) printf("mul2 mismatch M=%d\n", M); }
     fp_mul(t3, e, f); fp_add(r1, r1, t3); fp_mul3(r2, a, b, c, d, e, f); if (!eq(r1, r2) || !in_range(r2)) { ++bad; if (bad < 4) printf("mul3 mismatch M=%d\n", M); }
   }
+  // divstep inversion: x * x^-1 = 1 for random x in [0, 2p), plus 0 -> 0, 1 -> 1, p - 1 (= -1) -> itself
+  Fp<M> one; fp_one(one);
+  for (int it = 0; it < 300; ++it) {
+    Fp<M> x, ix, prod;
+    rand_fp(x);
+    if (it == 0) x = one;
+    if (it == 1) { Fp<M> z; fp_zero(z); fp_sub(x, z, one); }
+    fp_inv(ix, x);
+    fp_mul(prod, x, ix);
+    if (!eq(prod, one) || !in_range(ix)) { ++bad; if (bad < 6) printf("inv mismatch M=%d it=%d\n", M, it); }
+  }
+  { Fp<M> z, iz; fp_zero(z); fp_inv(iz, z); if (!fp_is_zero(iz)) { ++bad; printf("inv(0) != 0, M=%d\n", M); } }
   return bad;
 }
-int main() { int b = run<0>() + run<1>(); printf(b ? "FAIL %d\n" : "fp_sqr / fp_mul2 / fp_mul3 OK\n", b); return b != 0; }
+int main() { int b = run<0>() + run<1>(); printf(b ? "FAIL %d\n" : "fp_sqr / fp_mul2 / fp_mul3 / fp_inv OK\n", b); return b != 0; }
