@@ -124,6 +124,11 @@ def main():
         achieved = ALGO_BYTES_PER_PAIR * n / (acc * 1e-3) / 1e9
         plan = pkg.msm_last_plan()
         plan_c, windows = plan["window_bits"], plan["windows"]
+        levels = plan.get("pair_levels", 0)
+        # Montgomery products per sorted entry: 6 per affine pair addition (3 + 3 for the simultaneous inversion) on 1/2, 1/4, ...
+        # of the entries, ~94 / batch for the divstep inversion, 11 per mixed addition on what is left
+        prod_per_entry = sum((6.0 + 94.0 / (155.0 if l == 1 else 96.0)) / 2 ** l for l in range(1, levels + 1)) + 11.0 / 2 ** levels
+        kernel_name = "k_bucket_accumulate<Mnt4G1>" if levels == 0 else f"k_pair_add<Mnt4G1> x{levels} + k_bucket_accumulate<Mnt4G1>"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01", "accumulate_traffic.json")
         if os.path.exists(tpath) and args.log_n == LOG_N:
@@ -147,11 +152,14 @@ def main():
                        "window_table": plan["window_table"],
                        "parallelism": f"slice-per-gpu x{world}, all_gather of one projective point per rank"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": "k_bucket_accumulate<Mnt4G1>", "kernel_ms": acc,
+                         "traffic": traffic, "kernel": kernel_name, "kernel_ms": acc,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PAIR * n,
-                         "note": "integer-ALU bound, not HBM bound: 11 Montgomery products per bucket addition, windows x 2^20 additions per launch",
-                         "modmul_per_s": 11.0 * windows * n / (acc * 1e-3), "modmul_peak_per_s": MODMUL_PEAK_PER_S,
-                         "modmul_frac": 11.0 * windows * n / (acc * 1e-3) / MODMUL_PEAK_PER_S},
+                         "note": "bucket accumulation phase of one MSM (HIP events on the launch stream): integer-ALU bound in the "
+                                 "projective accumulate, scattered-HBM-sector bound in the first pairing level; far from the streaming HBM roof either way",
+                         "pair_levels": levels, "products_per_entry": prod_per_entry,
+                         "modmul_per_s": prod_per_entry * windows * n / (acc * 1e-3), "modmul_peak_per_s": MODMUL_PEAK_PER_S,
+                         "modmul_frac": prod_per_entry * windows * n / (acc * 1e-3) / MODMUL_PEAK_PER_S,
+                         "mixed_addition_equivalents_per_s": windows * n / (acc * 1e-3)},
             "phases_ms": {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},
         }
         if world == 1 and not args.no_cpu_baseline:

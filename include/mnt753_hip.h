@@ -106,6 +106,8 @@ int mnt753_msm_last_timing(float out_ms[5]);
 /* plan of the last mnt753_msm call: [0] window bits c, [1] windows W, [2] 1 if the precomputed window table was used,
  * [3] sorted entries per accumulate lane T */
 int mnt753_msm_last_plan(int out[4]);
+/* Levels of the batched-affine pairing pass the last G1 MSM ran before its accumulate kernel (0 = none). */
+int mnt753_msm_last_pair_levels(void);
 
 /* ---- small group operations on the host (O(1) work per proof) ------------------------------------ */
 /* replaces B::G1_add (hpp:32) */

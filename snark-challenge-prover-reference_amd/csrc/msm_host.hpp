@@ -14,6 +14,7 @@
 #include "host_field.hpp"
 #include "msm_kernels.cuh"
 #include "msm_types.hpp"
+#include "mnt753_generators.h"
 
 using namespace mnt753;
 
@@ -21,6 +22,7 @@ namespace mnt753 {
 extern int g_window_bits_override;
 extern float g_last_timing[5];
 extern int g_last_plan[4];
+extern int g_last_pair_levels;
 }
 namespace {
 
@@ -103,10 +105,20 @@ int point_lanes() {
   if constexpr (std::is_void<CS>::value) return 1;
   else return use_split_acc<C>() ? CS::F::LANES : 1;
 }
+void free_pair_ws(mnt753_bases* b) {
+  void* ptrs[] = {b->d_cnt2, b->d_pair_ws, b->d_fix, b->d_gen, b->d_offsets2[0], b->d_offsets2[1], b->d_pairpts[0], b->d_pairpts[1],
+                  b->d_sorted2[0], b->d_sorted2[1]};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  b->d_cnt2 = b->d_pair_ws = b->d_fix = b->d_gen = nullptr;
+  for (int k = 0; k < 2; ++k) b->d_offsets2[k] = b->d_pairpts[k] = b->d_sorted2[k] = nullptr;
+  b->pair_cap = 0;
+}
+
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
                   b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage, b->d_raw_buckets, b->d_raw_edges, b->d_bucket_state};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  free_pair_ws(b);
   if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
   b->d_digits = nullptr; b->d_hist = b->d_offsets = b->d_cursor = b->d_blocksums = b->d_total = nullptr;
   b->d_edge_tmp = b->d_edge_flags = nullptr;
@@ -147,6 +159,9 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   b->ws_plan = p;
   return 0;
 }
+
+template <class V> int pair_levels(uint64_t entries);
+template <class V> int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p);
 
 template <class C>
 int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_t n) {
@@ -197,6 +212,8 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   {
     MsmPlan p = make_plan(n, b->pre_c, point_lanes<C>());
     if (int rc = ensure_ws<C>(b, n, p)) return rc;
+    if (pair_levels<C>((uint64_t)p.T * p.n_lanes) > 0)
+      if (int rc = ensure_pair_ws<C>(b, p)) return rc;
     for (int i = 0; i < 5; ++i)
       if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
   }
@@ -216,6 +233,101 @@ void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
   acc.to_wire(out);
 }
 
+// Pairing passes (k_pair_add, MNT753_MSM_PAIR = number of levels) + accumulate over the shortened list; base-field groups.
+constexpr uint32_t PAIR_MAX_LANES = 131072;   // two rounds of the machine at two waves per SIMD
+constexpr uint32_t PAIR_MIN_B = 96;           // additions per inversion: keeps its share below one product per addition
+// levels of the pairing pass for an MSM with `entries` sorted entries: measured crossover on MI355X is ~2^19 points
+// (below it the per-level inversion latency and the short batches cost more than the saved products);
+// MNT753_MSM_PAIR=<levels> overrides, 0 turns it off
+template <class V>
+int pair_levels(uint64_t entries) {
+  if constexpr (V::F::DEG != 1 || V::F::LANES != 1) return 0;
+  else {
+    if (const char* e = getenv("MNT753_MSM_PAIR")) { int v = atoi(e); return v < 0 ? 0 : (v > 6 ? 6 : v); }
+    if (entries >= ((uint64_t)1 << 25)) return 3;
+    if (entries >= ((uint64_t)1 << 24)) return 2;
+    return 0;
+  }
+}
+// buffers of the pairing passes for an MSM with plan p (allocated with the base set when MNT753_MSM_PAIR is set)
+template <class V>
+int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p) {
+  if constexpr (V::F::DEG == 1 && V::F::LANES == 1) {
+    const uint64_t entries = (uint64_t)p.T * p.n_lanes;
+    const uint64_t cap1 = (entries + p.n_buckets) / 2 + 2;
+    const uint32_t max_lanes = PAIR_MAX_LANES;
+    const uint32_t min_B = PAIR_MIN_B;
+    if (b->pair_cap >= cap1) return 0;
+    {
+      free_pair_ws(b);
+      const uint64_t cap2 = (cap1 + p.n_buckets) / 2 + 2;
+      HIP_TRY(hipMalloc(&b->d_cnt2, sizeof(uint32_t) * ((size_t)p.n_buckets + 1)));
+      HIP_TRY(hipMalloc(&b->d_fix, sizeof(uint32_t) * (size_t)p.n_buckets));
+      HIP_TRY(hipMalloc(&b->d_gen, sizeof(uint32_t) * aff_words<V>()));
+      for (int k = 0; k < 2; ++k) {
+        const uint64_t cap = k == 0 ? cap1 : cap2;
+        HIP_TRY(hipMalloc(&b->d_offsets2[k], sizeof(uint32_t) * ((size_t)p.n_buckets + 1)));
+        HIP_TRY(hipMalloc(&b->d_pairpts[k], sizeof(uint32_t) * aff_words<V>() * cap));
+        HIP_TRY(hipMalloc(&b->d_sorted2[k], sizeof(uint32_t) * cap));
+      }
+      const uint64_t B1 = std::max<uint64_t>((cap1 + max_lanes - 1) / max_lanes, min_B);
+      HIP_TRY(hipMalloc(&b->d_pair_ws, sizeof(uint32_t) * FPS_WORDS * (size_t)(B1 + 1) * max_lanes));
+      // D: the group generator in device form (wire constant -> k_bases_to_internal)
+      uint32_t* wire = nullptr; uint8_t* inf = nullptr;
+      HIP_TRY(hipMalloc(&wire, 192)); HIP_TRY(hipMalloc(&inf, 16));
+      HIP_TRY(hipMemcpy(wire, b->curve == MNT753_CURVE_MNT4753 ? GEN_MNT4_G1 : GEN_MNT6_G1, 192, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((k_bases_to_internal<V>), dim3(1), dim3(256), 0, 0, wire, b->d_gen, inf, (size_t)1);
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(wire)); HIP_TRY(hipFree(inf));
+      b->pair_cap = cap1;
+    }
+    return 0;
+  } else {
+    (void)b; (void)p;
+    return 0;
+  }
+}
+template <class V>
+int pair_and_accumulate(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, int levels, uint32_t* acc_lanes) {
+  if constexpr (V::F::DEG == 1 && V::F::LANES == 1) {
+    const uint64_t entries = (uint64_t)p.T * p.n_lanes;                       // upper bound of the sorted entries
+    const uint64_t cap1 = (entries + p.n_buckets) / 2 + 2;                    // sum over the buckets of ceil(count / 2)
+    const uint32_t max_lanes = PAIR_MAX_LANES;
+    const uint32_t min_B = PAIR_MIN_B;
+    if (int rc = ensure_pair_ws<V>(b, p)) return rc;
+    HIP_TRY(hipMemsetAsync(b->d_fix, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
+    const uint32_t* cur_table = d_aff;
+    const uint32_t* cur_sorted = b->d_sorted;
+    const uint32_t* cur_offsets = b->d_offsets;
+    uint64_t cap = entries;
+    const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    for (int l = 0; l < levels; ++l) {
+      const int k = l & 1;
+      cap = (cap + p.n_buckets) / 2 + 2;
+      const uint32_t B = (uint32_t)std::max<uint64_t>((cap + max_lanes - 1) / max_lanes, min_B);
+      const uint32_t lanes = (uint32_t)((cap + B - 1) / B);
+      hipLaunchKernelGGL(k_pair_counts, dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, cur_offsets, b->d_cnt2, p.n_buckets);
+      hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_cnt2, b->d_offsets2[k], b->d_blocksums, (size_t)p.n_buckets);
+      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
+      hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets2[k], b->d_cnt2, b->d_blocksums, b->d_total,
+                         (size_t)p.n_buckets);
+      hipLaunchKernelGGL((k_pair_add<V>), dim3((lanes + 255) / 256), dim3(256), 0, st, cur_table, cur_sorted, cur_offsets, b->d_offsets2[k],
+                         p.n_buckets, b->d_pairpts[k], b->d_sorted2[k], b->d_pair_ws, B, lanes, b->d_gen, b->d_fix);
+      cur_table = b->d_pairpts[k]; cur_sorted = b->d_sorted2[k]; cur_offsets = b->d_offsets2[k];
+    }
+    // accumulate over at most `cap` entries: one round of the machine
+    const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, 65536u);
+    const uint32_t T2 = (uint32_t)std::max<uint64_t>((cap + lanes_acc - 1) / lanes_acc, 8);
+    hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, cur_table, cur_sorted,
+                       cur_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc);
+    *acc_lanes = lanes_acc;
+    return 0;
+  } else {
+    (void)p; (void)st; (void)d_aff; (void)b; (void)levels; (void)acc_lanes;
+    return 0;
+  }
+}
+
 // The stages that run point arithmetic.  V = the configuration the point-operation VM is instantiated with (C itself,
 // or its lane-split counterpart); kernels that only move points are layout-agnostic and use C.
 template <class V, class C>
@@ -227,6 +339,9 @@ int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753
   // programs of vm_uniform.cuh (MNT753_MSM_ACC=uniform)
   bool uniform_acc = false;
   if (const char* e = getenv("MNT753_MSM_ACC")) uniform_acc = strcmp(e, "uniform") == 0;
+  const int n_pair_levels = uniform_acc ? 0 : pair_levels<V>((uint64_t)p.T * p.n_lanes);
+  uint32_t acc_lanes = p.n_lanes;   // lanes the accumulate kernel ran with (= edge slots / 2)
+  g_last_pair_levels = n_pair_levels;
   if (uniform_acc) {
     HIP_TRY(hipMemsetAsync(b->d_bucket_state, 0, (size_t)p.n_buckets, st));
     hipLaunchKernelGGL((k_bucket_accumulate_u<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
@@ -235,6 +350,8 @@ int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753
                        b->d_bucket_state, (const uint32_t*)nullptr, p.n_buckets);
     hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_raw_edges, b->d_edges,
                        (const uint8_t*)nullptr, b->d_edge_bucket, 2 * p.n_lanes);
+  } else if (n_pair_levels > 0) {
+    if (int rc = pair_and_accumulate<V>(p, st, d_aff, b, n_pair_levels, &acc_lanes)) return rc;
   } else {
     if (mask & 1u)
       hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
@@ -245,7 +362,7 @@ int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753
   }
   HIP_TRY(hipEventRecord(b->ev[2], st));
   {
-    const uint32_t n_slots = 2 * p.n_lanes;
+    const uint32_t n_slots = 2 * acc_lanes;
     const unsigned gs = (n_slots + 255) / 256, gv = blocks_for<typename V::F>(n_slots);
     HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));
     uint32_t level = 0;
@@ -260,6 +377,10 @@ int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753
                          b->d_edge_flags, level);
     }
     hipLaunchKernelGGL((k_edge_finish<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_buckets, n_slots);
+    if constexpr (V::F::DEG == 1 && V::F::LANES == 1) {
+      if (n_pair_levels > 0)
+        hipLaunchKernelGGL((k_pair_fix<V>), dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, b->d_buckets, b->d_fix, b->d_gen, p.n_buckets);
+    }
   }
   if (mask & 4u)
     hipLaunchKernelGGL((k_bucket_reduce<V>), dim3(blocks_for<typename V::F>(p.n_chunks)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,

@@ -430,6 +430,158 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
   }
 }
 
+// ---- pairing pass: batched affine additions ahead of the accumulate (G1) ------------------------------------
+// The sorted entry list is halved before the projective accumulate: inside every bucket, entries (2j, 2j+1) are added in
+// AFFINE coordinates -- 3 products (lambda, lambda^2, y3) plus 3 for Montgomery's simultaneous-inversion trick plus a
+// 1/B share of one divstep inversion (fp_inv.cuh, ~94 product-equivalents) instead of the 11 of a mixed addition.
+// A lane owns B consecutive OUTPUT slots: forward sweep (running product of the denominators, prefix products to a
+// per-lane HBM workspace), one inversion, backward sweep (individual inverses, the sums).  Output: an affine point array
+// `pairpts` in the row format of the base table, a new entry list `sorted2` (slot -> row, no sign) and the bucket offsets
+// `offsets2` (scan of ceil(count / 2)), i.e. exactly the inputs of k_bucket_accumulate.
+// Side paths: an odd leftover is copied (with its sign applied); equal points are doubled (denominator 2y); opposite
+// points cancel: the slot gets the fixed point D (`gen`, the group generator) and fix_count[bucket] is incremented --
+// k_pair_fix subtracts fix_count * D from those buckets after the edge merge.  (The accumulate kernel is left exactly as
+// it is: every edit of its loop, even a skip test, cost 8-10 % through register allocation.)
+static __global__ void __launch_bounds__(256) k_pair_counts(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cnt2, uint32_t n_buckets) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_buckets) cnt2[b] = (offsets[b + 1] - offsets[b] + 1u) >> 1;
+}
+
+template <class C>
+__device__ __forceinline__ void pair_load(typename C::F::E& x, typename C::F::E& y, const uint32_t* __restrict__ table, uint32_t s) {
+  using F = typename C::F;
+  const uint32_t* src = table + (size_t)(s & 0x7fffffffu) * aff_words<C>();
+  e_load<F>(x, src);
+  e_load<F>(y, src + F::DEG * FPS_WORDS);
+  if (s & 0x80000000u) F::neg(y, y);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict__ table, const uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ offsets2,
+                                                    uint32_t n_buckets, uint32_t* __restrict__ pairpts, uint32_t* __restrict__ sorted2,
+                                                    uint32_t* __restrict__ prefix_ws, uint32_t B, uint32_t n_lanes,
+                                                    const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count) {
+  using F = typename C::F;
+  using E = typename F::E;
+  static_assert(F::DEG == 1 && F::LANES == 1, "pairing pass: base-field groups only");
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_lanes) return;
+  const uint32_t total2 = offsets2[n_buckets];
+  const uint64_t o0_64 = (uint64_t)t * B;
+  if (o0_64 >= total2) return;
+  const uint32_t o0 = (uint32_t)o0_64;
+  const uint32_t o1 = (o0_64 + B < total2) ? (uint32_t)(o0_64 + B) : total2;
+  uint32_t lo = 0, hi = n_buckets;   // largest b with offsets2[b] <= o0
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offsets2[mid + 1] > o0) hi = mid; else lo = mid + 1;
+  }
+  uint32_t b = lo;
+  uint32_t nxt = offsets2[b + 1];
+  E run, x1, y1, x2, y2, den, tmp;
+  F::one(run);
+  // ---- forward: prefix products of the denominators
+  for (uint32_t o = o0; o < o1; ++o) {
+    while (o == nxt) { ++b; nxt = offsets2[b + 1]; }
+    const uint32_t e0 = offsets[b] + 2u * (o - offsets2[b]);
+    e_store<F>(prefix_ws + ((size_t)(o - o0) * n_lanes + t) * FPS_WORDS, run);
+    if (e0 + 1u < offsets[b + 1]) {
+      const uint32_t s0 = sorted[e0], s1 = sorted[e0 + 1u];
+      // x only: the rows are gathered at random and this pass is bound by scattered HBM sectors, not by arithmetic
+      e_load<F>(x1, table + (size_t)(s0 & 0x7fffffffu) * aff_words<C>());
+      e_load<F>(x2, table + (size_t)(s1 & 0x7fffffffu) * aff_words<C>());
+      F::sub(den, x2, x1);
+      if (F::is_zero(den)) {
+        pair_load<C>(x1, y1, table, s0);
+        pair_load<C>(x2, y2, table, s1);
+        F::add(den, y1, y2);                 // equal points: 2y; opposite points: 0 -> take 1
+        if (F::is_zero(den)) F::one(den);
+      }
+      F::mul(tmp, run, den);
+      run = tmp;
+    }
+  }
+  E inv;
+  fp_inv(inv, run);
+  // ---- backward: individual inverses and the sums
+  for (uint32_t o = o1; o-- > o0;) {
+    while (o < offsets2[b]) --b;
+    const uint32_t e0 = offsets[b] + 2u * (o - offsets2[b]);
+    uint32_t* dst = pairpts + (size_t)o * aff_words<C>();
+    pair_load<C>(x1, y1, table, sorted[e0]);
+    if (!(e0 + 1u < offsets[b + 1])) {       // odd leftover: copy
+      e_store<F>(dst, x1);
+      e_store<F>(dst + F::DEG * FPS_WORDS, y1);
+      sorted2[o] = o;
+      continue;
+    }
+    pair_load<C>(x2, y2, table, sorted[e0 + 1u]);
+    E lam, pre, invj;
+    F::sub(den, x2, x1);
+    int kind = 0;                            // 0 = addition, 1 = doubling, 2 = cancellation
+    if (F::is_zero(den)) {
+      F::add(den, y1, y2);
+      if (F::is_zero(den)) { F::one(den); kind = 2; } else kind = 1;
+    }
+    e_load<F>(pre, prefix_ws + ((size_t)(o - o0) * n_lanes + t) * FPS_WORDS);
+    F::mul(invj, inv, pre);                  // 1 / den
+    F::mul(tmp, inv, den);                   // inverse of the product of the remaining denominators
+    inv = tmp;
+    if (kind == 2) {                         // P + (-P): emit D, remember to take it out of bucket b again
+      e_load<F>(x2, gen);
+      e_load<F>(y2, gen + F::DEG * FPS_WORDS);
+      e_store<F>(dst, x2);
+      e_store<F>(dst + F::DEG * FPS_WORDS, y2);
+      sorted2[o] = o;
+      atomicAdd(&fix_count[b], 1u);
+      continue;
+    }
+    if (kind == 0) {
+      F::sub(lam, y2, y1);
+    } else {                                 // 3 x^2 + a
+      F::mul(tmp, x1, x1);
+      F::add(lam, tmp, tmp); F::add(lam, lam, tmp);
+      C::coeff_a(tmp);
+      F::add(lam, lam, tmp);
+    }
+    F::mul(tmp, lam, invj);
+    lam = tmp;
+    F::mul(tmp, lam, lam);                   // x3 = lambda^2 - x1 - x2
+    F::sub(tmp, tmp, x1);
+    F::sub(x2, tmp, x2);
+    F::sub(tmp, x1, x2);                     // y3 = lambda (x1 - x3) - y1
+    F::mul(den, lam, tmp);
+    F::sub(y2, den, y1);
+    e_store<F>(dst, x2);
+    e_store<F>(dst + F::DEG * FPS_WORDS, y2);
+    sorted2[o] = o;
+  }
+}
+
+// buckets[b] -= fix_count[b] * D for the buckets in which the pairing pass replaced a cancelled pair by D
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_pair_fix(uint32_t* __restrict__ buckets, const uint32_t* __restrict__ fix_count,
+                                                    const uint32_t* __restrict__ gen, uint32_t n_buckets) {
+  using F = typename C::F;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_buckets) return;
+  const uint32_t k = fix_count[b];
+  if (k == 0) return;
+  Proj<C> acc, Q;
+  proj_load<C>(acc, buckets + (size_t)b * proj_words<C>());
+  e_load<F>(Q.X, gen);
+  e_load<F>(Q.Y, gen + F::DEG * FPS_WORDS);
+  F::neg(Q.Y, Q.Y);
+  F::one(Q.Z);
+  for (uint32_t i = 0; i < k; ++i) {
+    int pc = PC_MADD;
+    if (pt_is_zero(acc)) { acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z); pc = PC_END; }
+    pt_vm<C, false>(acc, Q, pc);
+  }
+  proj_store<C>(buckets + (size_t)b * proj_words<C>(), acc);
+}
+
 // ---- bucket accumulation, wave-uniform version (vm_uniform.cuh) ------------------------------------------
 // Same lane schedule as k_bucket_accumulate (lane t sums sorted entries [t*T, (t+1)*T), whole buckets go to the
 // bucket array, the first / last partial run to the edge slots), but:

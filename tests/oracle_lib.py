@@ -49,6 +49,15 @@ def field_op(mod, op, a, b=None):
     return out
 
 
+def neg_fq(curve, y):
+    """-y for base-field coordinates (G1): y is one element (12 words) or an array of them; Fq of MNT4753 is modulus B (1)."""
+    y = np.asarray(y, dtype=np.uint64)
+    mod = 1 if curve == 0 else 0
+    if y.ndim == 1:
+        return field_op(mod, 5, y)
+    return np.stack([field_op(mod, 5, row) for row in y])
+
+
 def point_op(curve, group, op, p, q=None):
     p = _arr(p); out = np.zeros(aff_words(curve, group), dtype=np.uint64)
     qq = _arr(q) if q is not None else np.zeros(max(12, aff_words(curve, group)), dtype=np.uint64)

@@ -212,3 +212,43 @@ def test_g2_lane_split_repeatable_at_sizes_that_faulted_with_dpp(gpu):
                 assert np.array_equal(gpu.point_to_affine(0, 2, bs.msm(sc)), exp)
         finally:
             bs.close()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("levels", [1, 2, 3, 4])
+def test_g1_pairing_pass_small_with_special_cases(gpu, curve, levels, monkeypatch):
+    """The batched-affine pairing pass (default only for >= 2^19 points) forced on a small G1 set that contains every side
+    path: equal points in one bucket (affine doubling), opposite points (the pair cancels: the slot carries the generator and
+    k_pair_fix takes it out of the bucket again), identity bases, zero / one scalars, an odd leftover per bucket -- with and
+    without the window table.  Result = oracle, bit-exact."""
+    n = 260
+    pts = gpu.synth_points(curve, 1, 31, n); sc = gpu.synth_scalars(curve, 32, n)
+    pts[0] = 0; pts[n - 1] = 0
+    pts[10] = pts[11]; sc[10] = sc[11]                       # P + P
+    pts[21] = pts[20]; pts[21, 12:] = O.neg_fq(curve, pts[20, 12:]); sc[21] = sc[20]   # P + (-P)
+    for k in range(40, 60): pts[k] = pts[40]; sc[k] = sc[40]  # twenty copies: doublings at every level
+    sc[3] = 0; sc[4] = gpu.api.mont_one(curve)
+    want = O.msm(curve, 1, pts, sc)
+    for table in ("0", "1"):
+        monkeypatch.setenv("MNT753_MSM_PRECOMP", table)
+        monkeypatch.setenv("MNT753_MSM_PAIR", str(levels))
+        bs = gpu.BaseSet(curve, 1, pts)
+        try:
+            assert np.array_equal(gpu.point_to_affine(curve, 1, bs.msm(sc)), want)
+            monkeypatch.setenv("MNT753_MSM_PAIR", "0")
+            assert np.array_equal(gpu.point_to_affine(curve, 1, bs.msm(sc)), want)
+        finally:
+            bs.close()
+
+
+def test_g1_pairing_pass_many_cancellations(gpu, monkeypatch):
+    """Every base appears together with its negative under the same scalar: every pair of the first level cancels, all
+    buckets go through the fix-up kernel, and the sum is the identity."""
+    monkeypatch.setenv("MNT753_MSM_PAIR", "3")
+    n = 512
+    half = gpu.synth_points(0, 1, 33, n // 2); sc_half = gpu.synth_scalars(0, 34, n // 2)
+    pts = np.concatenate([half, half]); pts[n // 2:, 12:] = O.neg_fq(0, half[:, 12:])
+    sc = np.concatenate([sc_half, sc_half])
+    got = gpu_msm_affine(gpu, 0, 1, pts, sc)
+    assert not got.any()
+    assert np.array_equal(got, O.msm(0, 1, pts, sc))
