@@ -234,8 +234,11 @@ void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
 }
 
 // Pairing passes (k_pair_add, MNT753_MSM_PAIR = number of levels) + accumulate over the shortened list; base-field groups.
-constexpr uint32_t PAIR_MAX_LANES = 131072;   // two rounds of the machine at two waves per SIMD
-constexpr uint32_t PAIR_MIN_B = 96;           // additions per inversion: keeps its share below one product per addition
+// lanes per pairing level (two rounds of the machine at two waves per SIMD) and minimum additions per inversion (keeps its
+// share below one product per addition); MNT753_PAIR_LANES / MNT753_PAIR_MINB are development overrides
+inline uint32_t pair_env(const char* name, uint32_t dflt) { const char* e = getenv(name); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; }
+#define PAIR_MAX_LANES pair_env("MNT753_PAIR_LANES", 131072u)
+#define PAIR_MIN_B pair_env("MNT753_PAIR_MINB", 48u)
 // levels of the pairing pass for an MSM with `entries` sorted entries: measured crossover on MI355X is ~2^19 points
 // (below it the per-level inversion latency and the short batches cost more than the saved products);
 // MNT753_MSM_PAIR=<levels> overrides, 0 turns it off

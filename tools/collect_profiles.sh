@@ -45,4 +45,31 @@ for db in glob.glob(O + "/*/*_results.db"):
             open(f"{O}/{tag}_pmc_error.txt", "w").write(repr(ex))
     con.close(); os.remove(db)
 PY
+python3 - <<'PY'
+# HBM traffic of the bucket-accumulation phase of one G1 MSM: FETCH_SIZE / WRITE_SIZE (KB) summed over the kernels of the phase
+import csv, json, os
+O = os.path.join(os.getcwd(), "gpurun_out", "prof")
+def per_msm(f, ctr):
+    tot = 0.0; launches = {}
+    for r in csv.DictReader(open(f)):
+        n = r["kernel"]
+        if r["counter"] != ctr: continue
+        if "k_pair_add<mnt753::Mnt4G1>" in n or "k_bucket_accumulate<mnt753::Mnt4G1>" in n or "k_pair_fix" in n or "k_pair_counts" in n:
+            launches[n.split("(")[0]] = (int(r["launches"]), float(r["avg_value"]))
+    acc = [v for k, v in launches.items() if "k_bucket_accumulate" in k]
+    msms = acc[0][0] if acc else 1
+    for k, (cnt, avg) in launches.items(): tot += cnt * avg / msms
+    return tot, launches, msms
+try:
+    f, lf, m = per_msm(O + "/pmc_fetch_pmc.csv", "FETCH_SIZE"); w, lw, _ = per_msm(O + "/pmc_write_pmc.csv", "WRITE_SIZE")
+    json.dump({"phase": "bucket accumulation of one 2^20 G1 MSM: k_pair_add x levels + k_bucket_accumulate (+ k_pair_counts, k_pair_fix)",
+               "msms_averaged": m, "FETCH_SIZE_KB_per_msm": f, "WRITE_SIZE_KB_per_msm": w,
+               "raw_bytes_per_msm": (f + w) * 1024, "hbm_bytes_per_launch": (2 * f + w) * 1024,
+               "per_kernel_FETCH_KB": {k: {"launches": c, "avg": a} for k, (c, a) in lf.items()},
+               "per_kernel_WRITE_KB": {k: {"launches": c, "avg": a} for k, (c, a) in lw.items()},
+               "correction": "MI355X_MICROARCH.md HBM section: counters in KB; FETCH_SIZE doubled for 16-B-per-lane loads on gfx950 (row gathers: uncalibrated pattern, raw figure kept beside it)",
+               "algorithmic_bytes_per_launch": 301989888}, open(O + "/accumulate_traffic.json", "w"), indent=1)
+except Exception as ex:
+    open(O + "/accumulate_traffic_error.txt", "w").write(repr(ex))
+PY
 ls -la $O
