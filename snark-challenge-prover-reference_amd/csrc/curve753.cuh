@@ -13,6 +13,7 @@
 #pragma once
 #include <type_traits>
 #include "fp753.cuh"
+#include "fp_inv.cuh"
 
 namespace mnt753 {
 
@@ -28,6 +29,7 @@ struct FieldFp {
   static constexpr bool HAS_SQR = true;
   static HD void mul(E& r, const E& a, const E& b) { fp_mul(r, a, b); }
   static HD void sqr(E& r, const E& a) { fp_sqr(r, a); }
+  static HD void inv(E& r, const E& a) { fp_inv(r, a); }
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
   static HD void neg(E& r, const E& a) { fp_neg(r, a); }
@@ -193,6 +195,24 @@ struct FieldFp2S {
     for (int i = 0; i < NL; ++i) xo.l[i] = odd ? xo.l[i] : nx.l[i];
     fp_mul2(r, x, b1, xo, b2);
   }
+  // (x0 - x1 u) / (x0^2 - NR x1^2)   (fp2.tcc:129-142): each lane squares its component, the pair shares the norm,
+  // both lanes run the same base-field inversion
+  static HD void inv(E& r, const E& x) {
+    E sq, a0, a1, t, n, ni;
+    const bool odd = lane_is_odd();
+    fp_sqr(sq, x);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const uint32_t o = pair_swap_u32(sq.l[i]);
+      a0.l[i] = odd ? o : sq.l[i];
+      a1.l[i] = odd ? sq.l[i] : o;
+    }
+    fp_mul_small(t, a1, NR);
+    fp_sub(n, a0, t);
+    fp_inv(ni, n);
+    fp_mul(t, x, ni);
+    if (odd) fp_neg(r, t); else r = t;
+  }
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
   static HD void neg(E& r, const E& a) { fp_neg(r, a); }
@@ -253,6 +273,36 @@ struct FieldFp3S {
       x2.l[i] = (k == 0) ? n2.l[i] : x2.l[i];
     }
     fp_mul3(r, x, y0, x1, y2, x2, y1);
+  }
+  // fp3.tcc:126-143: c = (x0^2 - NR x1 x2, NR x2^2 - x0 x1, x1^2 - x0 x2), t = x0 c0 + NR (x2 c1 + x1 c2) = the
+  // constant coefficient of x * c, result c / t.  Lane k forms c_k as one fused two-product step.
+  static HD void inv(E& r, const E& x) {
+    const int lane = wave_lane(), k = lane % 3, g = lane - k;
+    E x0, x1, x2, a1, b1, a2, b2, t, c, p, ti;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      x0.l[i] = lane_fetch_u32(x.l[i], g);
+      x1.l[i] = lane_fetch_u32(x.l[i], g + 1);
+      x2.l[i] = lane_fetch_u32(x.l[i], g + 2);
+    }
+    E nx1, nx2, neg0, negn1;
+    fp_mul_small(nx1, x1, NR);
+    fp_mul_small(nx2, x2, NR);
+    fp_neg(neg0, x0);
+    fp_neg(negn1, nx1);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      a1.l[i] = k == 0 ? x0.l[i] : (k == 1 ? nx2.l[i] : x1.l[i]);
+      b1.l[i] = k == 0 ? x0.l[i] : (k == 1 ? x2.l[i] : x1.l[i]);
+      a2.l[i] = k == 0 ? negn1.l[i] : neg0.l[i];
+      b2.l[i] = k == 1 ? x1.l[i] : x2.l[i];
+    }
+    fp_mul2(c, a1, b1, a2, b2);
+    mul(p, x, c);                       // lane g holds t, the other two hold 0
+#pragma unroll
+    for (int i = 0; i < NL; ++i) t.l[i] = lane_fetch_u32(p.l[i], g);
+    fp_inv(ti, t);
+    fp_mul(r, c, ti);
   }
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }

@@ -161,7 +161,9 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
 }
 
 template <class V> int pair_levels(uint64_t entries);
-template <class V> int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p);
+template <class C> int pair_levels_for(uint64_t entries);
+template <class C> int ensure_pair_ws_for(mnt753_bases* b, const MsmPlan& p);
+template <class V, class C> int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p);
 
 template <class C>
 int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_t n) {
@@ -212,8 +214,8 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   {
     MsmPlan p = make_plan(n, b->pre_c, point_lanes<C>());
     if (int rc = ensure_ws<C>(b, n, p)) return rc;
-    if (pair_levels<C>((uint64_t)p.T * p.n_lanes) > 0)
-      if (int rc = ensure_pair_ws<C>(b, p)) return rc;
+    if (pair_levels_for<C>((uint64_t)p.T * p.n_lanes) > 0)
+      if (int rc = ensure_pair_ws_for<C>(b, p)) return rc;
     for (int i = 0; i < 5; ++i)
       if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
   }
@@ -239,26 +241,31 @@ void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
 inline uint32_t pair_env(const char* name, uint32_t dflt) { const char* e = getenv(name); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; }
 #define PAIR_MAX_LANES pair_env("MNT753_PAIR_LANES", 131072u)
 #define PAIR_MIN_B pair_env("MNT753_PAIR_MINB", 48u)
-// levels of the pairing pass for an MSM with `entries` sorted entries: measured crossover on MI355X is ~2^19 points
-// (below it the per-level inversion latency and the short batches cost more than the saved products);
+// levels of the pairing pass for an MSM with `entries` sorted entries: below the measured crossover the per-level
+// inversion latency and the short batches cost more than the saved products;
 // MNT753_MSM_PAIR=<levels> overrides, 0 turns it off
 template <class V>
 int pair_levels(uint64_t entries) {
-  if constexpr (V::F::DEG != 1 || V::F::LANES != 1) return 0;
+  if constexpr (V::F::DEG != 1 && V::F::LANES == 1) return 0;   // one-lane Fq2 / Fq3: the state does not fit, no pairing
   else {
     if (const char* e = getenv("MNT753_MSM_PAIR")) { int v = atoi(e); return v < 0 ? 0 : (v > 6 ? 6 : v); }
-    if (entries >= ((uint64_t)1 << 25)) return 3;
-    if (entries >= ((uint64_t)1 << 24)) return 2;
+    if constexpr (V::F::LANES == 1) {          // G1: crossover ~2^19 points
+      if (entries >= ((uint64_t)1 << 25)) return 3;
+      if (entries >= ((uint64_t)1 << 24)) return 2;
+    } else {                                   // lane-split G2: more arithmetic per gathered byte, crossover ~2^17 points
+      if (entries >= ((uint64_t)1 << 23)) return 3;
+      if (entries >= ((uint64_t)1 << 22)) return 2;
+    }
     return 0;
   }
 }
 // buffers of the pairing passes for an MSM with plan p (allocated with the base set when MNT753_MSM_PAIR is set)
-template <class V>
+template <class V, class C>
 int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p) {
-  if constexpr (V::F::DEG == 1 && V::F::LANES == 1) {
+  if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
     const uint64_t entries = (uint64_t)p.T * p.n_lanes;
     const uint64_t cap1 = (entries + p.n_buckets) / 2 + 2;
-    const uint32_t max_lanes = PAIR_MAX_LANES;
+    const uint32_t max_lanes = PAIR_MAX_LANES / (uint32_t)V::F::LANES;   // logical lanes
     const uint32_t min_B = PAIR_MIN_B;
     if (b->pair_cap >= cap1) return 0;
     {
@@ -274,12 +281,14 @@ int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p) {
         HIP_TRY(hipMalloc(&b->d_sorted2[k], sizeof(uint32_t) * cap));
       }
       const uint64_t B1 = std::max<uint64_t>((cap1 + max_lanes - 1) / max_lanes, min_B);
-      HIP_TRY(hipMalloc(&b->d_pair_ws, sizeof(uint32_t) * FPS_WORDS * (size_t)(B1 + 1) * max_lanes));
+      HIP_TRY(hipMalloc(&b->d_pair_ws, sizeof(uint32_t) * FPS_WORDS * V::F::DEG * (size_t)(B1 + 1) * max_lanes));
       // D: the group generator in device form (wire constant -> k_bases_to_internal)
       uint32_t* wire = nullptr; uint8_t* inf = nullptr;
-      HIP_TRY(hipMalloc(&wire, 192)); HIP_TRY(hipMalloc(&inf, 16));
-      HIP_TRY(hipMemcpy(wire, b->curve == MNT753_CURVE_MNT4753 ? GEN_MNT4_G1 : GEN_MNT6_G1, 192, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL((k_bases_to_internal<V>), dim3(1), dim3(256), 0, 0, wire, b->d_gen, inf, (size_t)1);
+      const size_t gen_bytes = 192 * (size_t)C::F::DEG;
+      const uint64_t* gen_wire = b->curve == MNT753_CURVE_MNT4753 ? (C::F::DEG == 1 ? GEN_MNT4_G1 : GEN_MNT4_G2) : (C::F::DEG == 1 ? GEN_MNT6_G1 : GEN_MNT6_G2);
+      HIP_TRY(hipMalloc(&wire, gen_bytes)); HIP_TRY(hipMalloc(&inf, 16));
+      HIP_TRY(hipMemcpy(wire, gen_wire, gen_bytes, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((k_bases_to_internal<C>), dim3(1), dim3(256), 0, 0, wire, b->d_gen, inf, (size_t)1);
       HIP_TRY(hipDeviceSynchronize());
       HIP_TRY(hipFree(wire)); HIP_TRY(hipFree(inf));
       b->pair_cap = cap1;
@@ -290,14 +299,27 @@ int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p) {
     return 0;
   }
 }
-template <class V>
+// workspace for the configuration the point kernels of group C currently run with
+template <class C>
+int ensure_pair_ws_for(mnt753_bases* b, const MsmPlan& p) {
+  using CS = typename SplitOf<C>::type;
+  if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return ensure_pair_ws<CS, C>(b, p); }
+  return ensure_pair_ws<C, C>(b, p);
+}
+template <class C>
+int pair_levels_for(uint64_t entries) {
+  using CS = typename SplitOf<C>::type;
+  if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return pair_levels<CS>(entries); }
+  return pair_levels<C>(entries);
+}
+template <class V, class C>
 int pair_and_accumulate(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, int levels, uint32_t* acc_lanes) {
-  if constexpr (V::F::DEG == 1 && V::F::LANES == 1) {
+  if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
     const uint64_t entries = (uint64_t)p.T * p.n_lanes;                       // upper bound of the sorted entries
     const uint64_t cap1 = (entries + p.n_buckets) / 2 + 2;                    // sum over the buckets of ceil(count / 2)
-    const uint32_t max_lanes = PAIR_MAX_LANES;
+    const uint32_t max_lanes = PAIR_MAX_LANES / (uint32_t)V::F::LANES;   // logical lanes
     const uint32_t min_B = PAIR_MIN_B;
-    if (int rc = ensure_pair_ws<V>(b, p)) return rc;
+    if (int rc = ensure_pair_ws<V, C>(b, p)) return rc;
     HIP_TRY(hipMemsetAsync(b->d_fix, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
     const uint32_t* cur_table = d_aff;
     const uint32_t* cur_sorted = b->d_sorted;
@@ -314,12 +336,12 @@ int pair_and_accumulate(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff,
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
       hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets2[k], b->d_cnt2, b->d_blocksums, b->d_total,
                          (size_t)p.n_buckets);
-      hipLaunchKernelGGL((k_pair_add<V>), dim3((lanes + 255) / 256), dim3(256), 0, st, cur_table, cur_sorted, cur_offsets, b->d_offsets2[k],
+      hipLaunchKernelGGL((k_pair_add<V>), dim3(blocks_for<typename V::F>(lanes)), dim3(256), 0, st, cur_table, cur_sorted, cur_offsets, b->d_offsets2[k],
                          p.n_buckets, b->d_pairpts[k], b->d_sorted2[k], b->d_pair_ws, B, lanes, b->d_gen, b->d_fix);
       cur_table = b->d_pairpts[k]; cur_sorted = b->d_sorted2[k]; cur_offsets = b->d_offsets2[k];
     }
     // accumulate over at most `cap` entries: one round of the machine
-    const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, 65536u);
+    const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, V::F::LANES == 3 ? 21504u : 65536u / (uint32_t)V::F::LANES);
     const uint32_t T2 = (uint32_t)std::max<uint64_t>((cap + lanes_acc - 1) / lanes_acc, 8);
     hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, cur_table, cur_sorted,
                        cur_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc);
@@ -354,7 +376,7 @@ int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753
     hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_raw_edges, b->d_edges,
                        (const uint8_t*)nullptr, b->d_edge_bucket, 2 * p.n_lanes);
   } else if (n_pair_levels > 0) {
-    if (int rc = pair_and_accumulate<V>(p, st, d_aff, b, n_pair_levels, &acc_lanes)) return rc;
+    if (int rc = pair_and_accumulate<V, C>(p, st, d_aff, b, n_pair_levels, &acc_lanes)) return rc;
   } else {
     if (mask & 1u)
       hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
@@ -380,9 +402,9 @@ int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753
                          b->d_edge_flags, level);
     }
     hipLaunchKernelGGL((k_edge_finish<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_buckets, n_slots);
-    if constexpr (V::F::DEG == 1 && V::F::LANES == 1) {
+    if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
       if (n_pair_levels > 0)
-        hipLaunchKernelGGL((k_pair_fix<V>), dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, b->d_buckets, b->d_fix, b->d_gen, p.n_buckets);
+        hipLaunchKernelGGL((k_pair_fix<V>), dim3(blocks_for<typename V::F>(p.n_buckets)), dim3(256), 0, st, b->d_buckets, b->d_fix, b->d_gen, p.n_buckets);
     }
   }
   if (mask & 4u)

@@ -23,7 +23,6 @@
 #include <hip/hip_runtime.h>
 #include "curve753.cuh"
 #include "vm_uniform.cuh"
-#include "fp_inv.cuh"
 
 namespace mnt753 {
 
@@ -464,8 +463,8 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
                                                     const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count) {
   using F = typename C::F;
   using E = typename F::E;
-  static_assert(F::DEG == 1 && F::LANES == 1, "pairing pass: base-field groups only");
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int EW = F::DEG * FPS_WORDS;   // storage words of one element (lane-split fields store their own component)
+  const uint32_t t = logical_lane<F>();
   if (t >= n_lanes) return;
   const uint32_t total2 = offsets2[n_buckets];
   const uint64_t o0_64 = (uint64_t)t * B;
@@ -485,7 +484,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
   for (uint32_t o = o0; o < o1; ++o) {
     while (o == nxt) { ++b; nxt = offsets2[b + 1]; }
     const uint32_t e0 = offsets[b] + 2u * (o - offsets2[b]);
-    e_store<F>(prefix_ws + ((size_t)(o - o0) * n_lanes + t) * FPS_WORDS, run);
+    e_store<F>(prefix_ws + ((size_t)(o - o0) * n_lanes + t) * EW, run);
     if (e0 + 1u < offsets[b + 1]) {
       const uint32_t s0 = sorted[e0], s1 = sorted[e0 + 1u];
       // x only: the rows are gathered at random and this pass is bound by scattered HBM sectors, not by arithmetic
@@ -503,7 +502,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
     }
   }
   E inv;
-  fp_inv(inv, run);
+  F::inv(inv, run);
   // ---- backward: individual inverses and the sums
   for (uint32_t o = o1; o-- > o0;) {
     while (o < offsets2[b]) --b;
@@ -524,7 +523,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
       F::add(den, y1, y2);
       if (F::is_zero(den)) { F::one(den); kind = 2; } else kind = 1;
     }
-    e_load<F>(pre, prefix_ws + ((size_t)(o - o0) * n_lanes + t) * FPS_WORDS);
+    e_load<F>(pre, prefix_ws + ((size_t)(o - o0) * n_lanes + t) * EW);
     F::mul(invj, inv, pre);                  // 1 / den
     F::mul(tmp, inv, den);                   // inverse of the product of the remaining denominators
     inv = tmp;
@@ -534,7 +533,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
       e_store<F>(dst, x2);
       e_store<F>(dst + F::DEG * FPS_WORDS, y2);
       sorted2[o] = o;
-      atomicAdd(&fix_count[b], 1u);
+      if (lane_comp<F>() == 0) atomicAdd(&fix_count[b], 1u);
       continue;
     }
     if (kind == 0) {
@@ -564,7 +563,7 @@ template <class C>
 __global__ void __launch_bounds__(256, 1) k_pair_fix(uint32_t* __restrict__ buckets, const uint32_t* __restrict__ fix_count,
                                                     const uint32_t* __restrict__ gen, uint32_t n_buckets) {
   using F = typename C::F;
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = logical_lane<F>();
   if (b >= n_buckets) return;
   const uint32_t k = fix_count[b];
   if (k == 0) return;

@@ -252,3 +252,36 @@ def test_g1_pairing_pass_many_cancellations(gpu, monkeypatch):
     got = gpu_msm_affine(gpu, 0, 1, pts, sc)
     assert not got.any()
     assert np.array_equal(got, O.msm(0, 1, pts, sc))
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("levels", [1, 3])
+def test_g2_pairing_pass_small_with_special_cases(gpu, curve, levels, monkeypatch):
+    """The pairing pass on the lane-split G2 kernels (default from ~2^17 points) forced on a small set with equal points
+    (affine doubling over Fq2 / Fq3), identity bases, zero / one scalars and odd leftovers, with and without the window table;
+    the extension-field inversion (norm shared across the 2 / 3 lanes of a point) is on this path.  Result = oracle."""
+    n = 130
+    pts = gpu.synth_points(curve, 2, 35, n); sc = gpu.synth_scalars(curve, 36, n)
+    pts[0] = 0; pts[n - 1] = 0
+    pts[10] = pts[11]; sc[10] = sc[11]
+    for k in range(40, 52): pts[k] = pts[40]; sc[k] = sc[40]
+    sc[3] = 0; sc[4] = gpu.api.mont_one(curve)
+    want = O.msm(curve, 2, pts, sc)
+    for table in ("0", "1"):
+        monkeypatch.setenv("MNT753_MSM_PRECOMP", table)
+        monkeypatch.setenv("MNT753_MSM_PAIR", str(levels))
+        assert np.array_equal(gpu_msm_affine(gpu, curve, 2, pts, sc), want)
+
+
+@pytest.mark.parametrize("curve,group", [(0, 2), (1, 2), (1, 1)])
+def test_pairing_pass_cancellations_every_group(gpu, curve, group, monkeypatch):
+    """P and -P under the same scalar for every base: all first-level pairs cancel and go through k_pair_fix (generator in,
+    generator out); checked on the groups not covered by test_g1_pairing_pass_many_cancellations."""
+    monkeypatch.setenv("MNT753_MSM_PAIR", "2")
+    n = 64
+    half = gpu.synth_points(curve, group, 37, n // 2); sc_half = gpu.synth_scalars(curve, 38, n // 2)
+    neg = np.stack([O.point_op(curve, group, 2, np.zeros_like(p), p) for p in half])   # O - P
+    pts = np.concatenate([half, neg]); sc = np.concatenate([sc_half, sc_half])
+    got = gpu_msm_affine(gpu, curve, group, pts, sc)
+    assert np.array_equal(got, O.msm(curve, group, pts, sc))
+    assert not got.any()
