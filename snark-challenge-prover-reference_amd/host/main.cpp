@@ -1,4 +1,4 @@
-// ./main_hip <curve> compute <params> <input> <output> [--fused-h] [--quiet]
+// ./main_hip <curve> compute <params> <input> <output> [--fused-h] [--h-first|--h-last] [--quiet]
 //
 // The prover driver, same command line as the reference binaries (libsnark/main.cpp:274-293,
 // cuda_prover_piecewise.cu:100-120).  compute_H<B> and run_prover<B> keep the reference's shape -- they are
@@ -15,6 +15,7 @@
 
 static bool g_fused_h = false;
 static bool g_quiet = false;
+static bool g_h_first = false;   // --h-first: compute_H and the H MSM before the other three G1 MSMs
 
 typedef std::chrono::steady_clock clk;
 static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
@@ -69,13 +70,27 @@ void run_prover(const char* params_path, const char* input_path, const char* out
   // as soon as w is on the device -- the long G2 one first, the short G1 ones run inside its latency-bound tail --
   // while ca / cb / cc are still loading; compute_H and the H MSM follow.
   typename B::G2* evaluation_Bt2 = B::multiexp_G2(w, pB2, B::params_m(params) + 1);
-  typename B::G1* evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
-  typename B::G1* evaluation_Bt1 = B::multiexp_G1(w, pB1, B::params_m(params) + 1);
+  typename B::G1 *evaluation_At, *evaluation_Bt1, *evaluation_Lt, *evaluation_Ht;
   auto w_off = B::vector_Fr_offset(w, primary_input_size + 1);
-  typename B::G1* evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
-  auto coefficients_for_H = compute_H<B>(B::params_d(params), ca, cb, cc);
+  typename B::vector_Fr* coefficients_for_H;
   auto t_h = clk::now();
-  typename B::G1* evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
+  if (g_h_first) {
+    // compute_H right behind the G2 MSM: its short kernels are not starved by four G1 accumulation phases, and the H MSM
+    // overlaps the others instead of running alone at the end
+    coefficients_for_H = compute_H<B>(B::params_d(params), ca, cb, cc);
+    t_h = clk::now();
+    evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
+    evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
+    evaluation_Bt1 = B::multiexp_G1(w, pB1, B::params_m(params) + 1);
+    evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
+  } else {
+    evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
+    evaluation_Bt1 = B::multiexp_G1(w, pB1, B::params_m(params) + 1);
+    evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
+    coefficients_for_H = compute_H<B>(B::params_d(params), ca, cb, cc);
+    t_h = clk::now();
+    evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
+  }
   // the five MSMs run concurrently on their base sets' streams; touching the results waits for them
   (void)B::G1_words(evaluation_At); (void)B::G1_words(evaluation_Bt1); (void)B::G2_words(evaluation_Bt2);
   (void)B::G1_words(evaluation_Ht); (void)B::G1_words(evaluation_Lt);
@@ -109,12 +124,14 @@ void run_prover(const char* params_path, const char* input_path, const char* out
 int main(int argc, char** argv) {
   setbuf(stdout, NULL);
   if (argc < 6) {
-    fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [--fused-h] [--quiet]\n", argv[0]);
+    fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [--fused-h] [--h-first|--h-last] [--quiet]\n", argv[0]);
     return 2;
   }
   for (int i = 6; i < argc; ++i) {
     if (!strcmp(argv[i], "--fused-h")) g_fused_h = true;
     else if (!strcmp(argv[i], "--quiet")) g_quiet = true;
+    else if (!strcmp(argv[i], "--h-first")) g_h_first = true;
+    else if (!strcmp(argv[i], "--h-last")) g_h_first = false;
   }
   std::string curve(argv[1]), mode(argv[2]);
   try {
