@@ -214,8 +214,12 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   {
     MsmPlan p = make_plan(n, b->pre_c, point_lanes<C>());
     if (int rc = ensure_ws<C>(b, n, p)) return rc;
-    if (pair_levels_for<C>((uint64_t)p.T * p.n_lanes) > 0)
-      if (int rc = ensure_pair_ws_for<C>(b, p)) return rc;
+    if (pair_levels_for<C>((uint64_t)p.T * p.n_lanes) > 0 && ensure_pair_ws_for<C>(b, p) != 0) {
+      // not enough HBM for the pairing buffers (~7 GB per 2^20 G1 points): keep the set usable without the pairing pass
+      free_pair_ws(b);
+      b->no_pair = 1;
+      (void)hipGetLastError();
+    }
     for (int i = 0; i < 5; ++i)
       if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
   }
@@ -364,7 +368,7 @@ int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753
   // programs of vm_uniform.cuh (MNT753_MSM_ACC=uniform)
   bool uniform_acc = false;
   if (const char* e = getenv("MNT753_MSM_ACC")) uniform_acc = strcmp(e, "uniform") == 0;
-  const int n_pair_levels = uniform_acc ? 0 : pair_levels<V>((uint64_t)p.T * p.n_lanes);
+  const int n_pair_levels = (uniform_acc || b->no_pair) ? 0 : pair_levels<V>((uint64_t)p.T * p.n_lanes);
   uint32_t acc_lanes = p.n_lanes;   // lanes the accumulate kernel ran with (= edge slots / 2)
   g_last_pair_levels = n_pair_levels;
   if (uniform_acc) {
