@@ -90,8 +90,8 @@ namespace {
 template <class C>
 int proj_w() { return proj_words<C>(); }
 
-// Lane-split accumulate (k_bucket_accumulate_s): default for the groups that have a split configuration (Fq2);
-// MNT753_MSM_ACC=vm forces the one-lane-per-point kernel.
+// Lane-split point kernels (FieldFp2S / FieldFp3S instantiations): default for the groups that have a split configuration
+// (G2 of both curves); MNT753_MSM_ACC=vm forces the one-lane-per-point kernels, =uniform the wave-uniform XYZZ accumulate.
 template <class C>
 bool use_split_acc() {
   if (std::is_void<typename SplitOf<C>::type>::value) return false;

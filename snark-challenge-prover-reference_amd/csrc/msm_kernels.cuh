@@ -6,19 +6,21 @@
 // The result is the same group element; the schedule is GPU-native:
 //
 //   k_bases_to_internal   wire affine bases -> device form (27x28-bit limbs, R'=2^756), once per base set
-//   k_scalar_digits       Montgomery scalar -> integer (as_bigint), signed radix-2^c Booth digits,
-//                         per-(window,bucket) histogram
+//   k_precompute_windows  window table 2^(cw) P_i (affine), once per base set: every window then indexes ONE bucket set
+//   k_scalar_digits       Montgomery scalar -> integer (as_bigint), signed radix-2^c Booth digits, bucket histogram
 //   scan                  exclusive prefix sum of the histogram (bucket offsets)
-//   k_scatter             counting-sort point indices by (window, bucket)
-//   k_bucket_accumulate   each lane sums exactly T consecutive sorted entries (perfect SIMD balance for
-//                         ANY digit distribution); whole buckets go straight to the bucket array,
-//                         the first / last partial run of each lane goes to an edge array
-//   k_edge_combine        sums the edge pieces that belong to one bucket
-//   k_bucket_reduce       per window, chunked running sums  sum_b (b+1)*B[b]
-//   k_tree_sum            per window, sums the chunk results
-//   k_points_to_wire      window sums -> wire form (projective, Montgomery R=2^768)
-//   host                  Horner over the windows (W*c doublings -- a serial chain of ~750 group
-//                         operations that one CPU core finishes in ~2 ms; one GPU lane would need 60 ms)
+//   k_scatter             counting-sort (table row, sign) by bucket
+//   k_pair_add (x levels) batched-affine additions of adjacent entries inside every bucket, one divstep inversion per
+//                         lane batch (large sets only); k_pair_fix undoes the stand-in of cancelled pairs
+//   k_bucket_accumulate   each lane sums exactly T consecutive entries (perfect SIMD balance for ANY digit
+//                         distribution); whole buckets go straight to the bucket array, the first / last partial run of
+//                         each lane goes to an edge array
+//   k_edge_level_*        pointer-jumping sum of the edge pieces that belong to one bucket
+//   k_bucket_reduce       chunked running sums  sum_b (b+1)*B[b]
+//   k_tree_sum            sums the chunk results
+//   k_points_to_wire      -> wire form (projective, Montgomery R=2^768)
+//   host                  only without the window table (small sets): Horner over the window sums
+// The G2 instantiations of the point kernels run on lane-split extension fields (curve753.cuh): 2 or 3 lanes per point.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve753.cuh"
@@ -29,9 +31,9 @@ namespace mnt753 {
 constexpr int FPS_WORDS = 28;            // storage words per base-field element (27 limbs + pad), 112 B
 constexpr uint32_t EDGE_NONE = 0xffffffffu;
 
-// waves per SIMD requested for the point-arithmetic kernels: G1 keeps its whole state in the 512-register file at one
-// wave per SIMD; the Fq2 / Fq3 kernels spill to scratch whatever the budget, and two waves per SIMD (256 registers) were measured 3x slower,
-// so they also run one wave per SIMD (MNT753_G2_WAVES to override at build time)
+// waves per SIMD requested for the point-arithmetic kernels: the base-field and lane-split instantiations keep their state in
+// the 512-register file at one wave per SIMD; the one-lane Fq2 / Fq3 kernels (MNT753_MSM_ACC=vm) spill whatever the budget and
+// two waves per SIMD (256 registers) were measured 3x slower (MNT753_G2_WAVES to override at build time)
 #ifndef MNT753_G2_WAVES
 #define MNT753_G2_WAVES 1
 #endif
