@@ -333,6 +333,7 @@ int pair_and_accumulate(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff,
     for (int l = 0; l < levels; ++l) {
       const int k = l & 1;
       cap = (cap + p.n_buckets) / 2 + 2;
+      // worst-case batch length (the workspace is sized for it); the kernel shortens it to the actual slot count
       const uint32_t B = (uint32_t)std::max<uint64_t>((cap + max_lanes - 1) / max_lanes, min_B);
       const uint32_t lanes = (uint32_t)((cap + B - 1) / B);
       hipLaunchKernelGGL(k_pair_counts, dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, cur_offsets, b->d_cnt2, p.n_buckets);
@@ -341,7 +342,7 @@ int pair_and_accumulate(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff,
       hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets2[k], b->d_cnt2, b->d_blocksums, b->d_total,
                          (size_t)p.n_buckets);
       hipLaunchKernelGGL((k_pair_add<V>), dim3(blocks_for<typename V::F>(lanes)), dim3(256), 0, st, cur_table, cur_sorted, cur_offsets, b->d_offsets2[k],
-                         p.n_buckets, b->d_pairpts[k], b->d_sorted2[k], b->d_pair_ws, B, lanes, b->d_gen, b->d_fix);
+                         p.n_buckets, b->d_pairpts[k], b->d_sorted2[k], b->d_pair_ws, min_B, lanes, b->d_gen, b->d_fix);
       cur_table = b->d_pairpts[k]; cur_sorted = b->d_sorted2[k]; cur_offsets = b->d_offsets2[k];
     }
     // accumulate over at most `cap` entries: one round of the machine

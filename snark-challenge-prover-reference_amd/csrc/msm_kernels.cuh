@@ -448,6 +448,32 @@ static __global__ void __launch_bounds__(256) k_pair_counts(const uint32_t* __re
   if (b < n_buckets) cnt2[b] = (offsets[b + 1] - offsets[b] + 1u) >> 1;
 }
 
+// Bucket walks of the pairing pass.  Buckets are usually adjacent, but a skewed scalar vector (all scalars equal: ~38
+// non-empty buckets out of 2^19) leaves thousands of empty ones between two slots, and a linear walk is one dependent load
+// per empty bucket in a lane the whole kernel then waits for: try the neighbour, else bisect.
+// first b' > b whose slot range ends after o (o < offs[n_buckets])
+__device__ __forceinline__ uint32_t bucket_after(const uint32_t* __restrict__ offs, uint32_t b, uint32_t o, uint32_t n_buckets) {
+  uint32_t lo = b + 1u;
+  if (offs[lo + 1u] > o) return lo;
+  uint32_t hi = n_buckets - 1u;
+  ++lo;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (offs[mid + 1u] > o) hi = mid; else lo = mid + 1u;
+  }
+  return lo;
+}
+// last b' < b whose slot range starts at or before o
+__device__ __forceinline__ uint32_t bucket_before(const uint32_t* __restrict__ offs, uint32_t b, uint32_t o) {
+  if (offs[b - 1u] <= o) return b - 1u;
+  uint32_t lo = 0, hi = b - 2u;              // offs[0] = 0 <= o
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1u) >> 1;
+    if (offs[mid] <= o) lo = mid; else hi = mid - 1u;
+  }
+  return lo;
+}
+
 template <class C>
 __device__ __forceinline__ void pair_load(typename C::F::E& x, typename C::F::E& y, const uint32_t* __restrict__ table, uint32_t s) {
   using F = typename C::F;
@@ -461,7 +487,7 @@ template <class C>
 __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict__ table, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ offsets2,
                                                     uint32_t n_buckets, uint32_t* __restrict__ pairpts, uint32_t* __restrict__ sorted2,
-                                                    uint32_t* __restrict__ prefix_ws, uint32_t B, uint32_t n_lanes,
+                                                    uint32_t* __restrict__ prefix_ws, uint32_t min_B, uint32_t n_lanes,
                                                     const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count) {
   using F = typename C::F;
   using E = typename F::E;
@@ -469,6 +495,9 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
   const uint32_t t = logical_lane<F>();
   if (t >= n_lanes) return;
   const uint32_t total2 = offsets2[n_buckets];
+  // batch length from the ACTUAL number of slots (the host only knows the worst case W * n): witness vectors full of zero
+  // and one scalars leave a fraction of it, and a fixed B would leave most lanes idle behind a few long batches
+  const uint32_t B = max(min_B, (total2 + n_lanes - 1u) / n_lanes);
   const uint64_t o0_64 = (uint64_t)t * B;
   if (o0_64 >= total2) return;
   const uint32_t o0 = (uint32_t)o0_64;
@@ -484,7 +513,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
   F::one(run);
   // ---- forward: prefix products of the denominators
   for (uint32_t o = o0; o < o1; ++o) {
-    while (o == nxt) { ++b; nxt = offsets2[b + 1]; }
+    if (o == nxt) { b = bucket_after(offsets2, b, o, n_buckets); nxt = offsets2[b + 1]; }
     const uint32_t e0 = offsets[b] + 2u * (o - offsets2[b]);
     e_store<F>(prefix_ws + ((size_t)(o - o0) * n_lanes + t) * EW, run);
     if (e0 + 1u < offsets[b + 1]) {
@@ -507,7 +536,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
   F::inv(inv, run);
   // ---- backward: individual inverses and the sums
   for (uint32_t o = o1; o-- > o0;) {
-    while (o < offsets2[b]) --b;
+    if (o < offsets2[b]) b = bucket_before(offsets2, b, o);
     const uint32_t e0 = offsets[b] + 2u * (o - offsets2[b]);
     uint32_t* dst = pairpts + (size_t)o * aff_words<C>();
     pair_load<C>(x1, y1, table, sorted[e0]);
