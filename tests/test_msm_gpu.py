@@ -285,3 +285,27 @@ def test_pairing_pass_cancellations_every_group(gpu, curve, group, monkeypatch):
     got = gpu_msm_affine(gpu, curve, group, pts, sc)
     assert np.array_equal(got, O.msm(curve, group, pts, sc))
     assert not got.any()
+
+
+@pytest.mark.parametrize("group,logn", [(1, 19), (2, 17)])
+def test_skewed_scalars_with_the_pairing_pass(gpu, group, logn):
+    """The same three skewed scalar vectors at sizes where the pairing pass runs by default (G1 2^19, G2 2^17): a handful of
+    giant buckets, thousands of empty ones between them (bisecting bucket walks), a sparse vector whose slot count is a
+    fraction of the worst case (batch length derived on the device).  Exact through the discrete logs, and bounded."""
+    n = 1 << logn
+    pts = gpu.synth_points(0, group, 93, n)
+    rnd = gpu.synth_scalars(0, 94, n)
+    one = gpu.api.mont_one(0)
+    bs = gpu.BaseSet(0, group, pts)
+    cases = [np.tile(rnd[0], (n, 1)), np.where((np.arange(n) % 2)[:, None] == 0, rnd[0], rnd[1])]
+    z = np.zeros_like(rnd); z[::2] = one; z[1::16] = rnd[1::16]
+    cases.append(z)
+    try:
+        for sc in cases:
+            sc = np.ascontiguousarray(sc)
+            got = gpu.point_to_affine(0, group, bs.msm(sc))
+            assert gpu.msm_last_plan()["pair_levels"] >= 2
+            assert np.array_equal(got, gpu.point_to_affine(0, group, gpu.synth_expected_msm(0, group, 93, sc)))
+            assert gpu.msm_last_timing()["total_ms"] < 300
+    finally:
+        bs.close()
