@@ -112,6 +112,7 @@ void free_pair_ws(mnt753_bases* b) {
   b->d_cnt2 = b->d_pair_ws = b->d_fix = b->d_gen = nullptr;
   for (int k = 0; k < 2; ++k) b->d_offsets2[k] = b->d_pairpts[k] = b->d_sorted2[k] = nullptr;
   b->pair_cap = 0;
+  b->pair_buckets = 0;
 }
 
 void free_ws(mnt753_bases* b) {
@@ -271,20 +272,23 @@ int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p) {
     const uint64_t cap1 = (entries + p.n_buckets) / 2 + 2;
     const uint32_t max_lanes = PAIR_MAX_LANES / (uint32_t)V::F::LANES;   // logical lanes
     const uint32_t min_B = PAIR_MIN_B;
-    if (b->pair_cap >= cap1) return 0;
+    if (b->pair_cap >= cap1 && b->pair_buckets >= p.n_buckets) return 0;
     {
+      // grow only: keep room for the largest plan this base set has run with
+      const uint64_t capA = std::max<uint64_t>(cap1, b->pair_cap);
+      const size_t nbA = std::max<size_t>(p.n_buckets, b->pair_buckets);
       free_pair_ws(b);
-      const uint64_t cap2 = (cap1 + p.n_buckets) / 2 + 2;
-      HIP_TRY(hipMalloc(&b->d_cnt2, sizeof(uint32_t) * ((size_t)p.n_buckets + 1)));
-      HIP_TRY(hipMalloc(&b->d_fix, sizeof(uint32_t) * (size_t)p.n_buckets));
+      const uint64_t cap2 = (capA + nbA) / 2 + 2;
+      HIP_TRY(hipMalloc(&b->d_cnt2, sizeof(uint32_t) * (nbA + 1)));
+      HIP_TRY(hipMalloc(&b->d_fix, sizeof(uint32_t) * nbA));
       HIP_TRY(hipMalloc(&b->d_gen, sizeof(uint32_t) * aff_words<V>()));
       for (int k = 0; k < 2; ++k) {
-        const uint64_t cap = k == 0 ? cap1 : cap2;
-        HIP_TRY(hipMalloc(&b->d_offsets2[k], sizeof(uint32_t) * ((size_t)p.n_buckets + 1)));
+        const uint64_t cap = k == 0 ? capA : cap2;
+        HIP_TRY(hipMalloc(&b->d_offsets2[k], sizeof(uint32_t) * (nbA + 1)));
         HIP_TRY(hipMalloc(&b->d_pairpts[k], sizeof(uint32_t) * aff_words<V>() * cap));
         HIP_TRY(hipMalloc(&b->d_sorted2[k], sizeof(uint32_t) * cap));
       }
-      const uint64_t B1 = std::max<uint64_t>((cap1 + max_lanes - 1) / max_lanes, min_B);
+      const uint64_t B1 = std::max<uint64_t>((capA + max_lanes - 1) / max_lanes, min_B);
       HIP_TRY(hipMalloc(&b->d_pair_ws, sizeof(uint32_t) * FPS_WORDS * V::F::DEG * (size_t)(B1 + 1) * max_lanes));
       // D: the group generator in device form (wire constant -> k_bases_to_internal)
       uint32_t* wire = nullptr; uint8_t* inf = nullptr;
@@ -295,7 +299,8 @@ int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p) {
       hipLaunchKernelGGL((k_bases_to_internal<C>), dim3(1), dim3(256), 0, 0, wire, b->d_gen, inf, (size_t)1);
       HIP_TRY(hipDeviceSynchronize());
       HIP_TRY(hipFree(wire)); HIP_TRY(hipFree(inf));
-      b->pair_cap = cap1;
+      b->pair_cap = capA;
+      b->pair_buckets = nbA;
     }
     return 0;
   } else {

@@ -38,6 +38,7 @@ struct mnt753_bases {
   uint32_t *d_cnt2 = nullptr, *d_pair_ws = nullptr, *d_fix = nullptr, *d_gen = nullptr;
   uint32_t *d_offsets2[2] = {nullptr, nullptr}, *d_pairpts[2] = {nullptr, nullptr}, *d_sorted2[2] = {nullptr, nullptr};   // ping-pong over the levels
   size_t pair_cap = 0;   // output slots of the first level the pairing buffers hold
+  size_t pair_buckets = 0;   // buckets the per-bucket pairing buffers hold
   int no_pair = 0;       // the pairing workspace could not be allocated: this set runs the plain accumulate
   uint32_t* d_wire_out = nullptr;
   uint64_t* h_wire_out = nullptr;   // pinned
