@@ -116,12 +116,12 @@ void free_pair_ws(mnt753_bases* b) {
 }
 
 void free_ws(mnt753_bases* b) {
-  void* ptrs[] = {b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
+  void* ptrs[] = {b->d_rank, b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
                   b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage, b->d_raw_buckets, b->d_raw_edges, b->d_bucket_state};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   free_pair_ws(b);
   if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
-  b->d_digits = nullptr; b->d_hist = b->d_offsets = b->d_cursor = b->d_blocksums = b->d_total = nullptr;
+  b->d_rank = nullptr; b->d_digits = nullptr; b->d_hist = b->d_offsets = b->d_cursor = b->d_blocksums = b->d_total = nullptr;
   b->d_edge_tmp = b->d_edge_flags = nullptr;
   b->d_raw_buckets = b->d_raw_edges = nullptr; b->d_bucket_state = nullptr;
   b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
@@ -136,6 +136,7 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   const size_t PW = proj_words<C>();
   const size_t nscan_blocks = ((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK;
   HIP_TRY(hipMalloc(&b->d_digits, sizeof(int32_t) * (size_t)p.W * n));
+  HIP_TRY(hipMalloc(&b->d_rank, sizeof(uint32_t) * (size_t)p.W * n));
   HIP_TRY(hipMalloc(&b->d_hist, sizeof(uint32_t) * (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_offsets, sizeof(uint32_t) * ((size_t)p.n_buckets + 1)));
   HIP_TRY(hipMalloc(&b->d_cursor, sizeof(uint32_t) * (size_t)p.n_buckets));
@@ -467,13 +468,13 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   HIP_TRY(hipEventRecord(b->ev[0], st));
   HIP_TRY(hipMemsetAsync(b->d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
   const unsigned gb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_hist, n, p.c, p.W, p.pre ? 0u : p.nb);
+  hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_rank, b->d_hist, n, p.c, p.W, p.pre ? 0u : p.nb);
   const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
   hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_hist, b->d_offsets, b->d_blocksums, (size_t)p.n_buckets);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
   hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total,
                      (size_t)p.n_buckets);
-  hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_cursor, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
+  hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_rank, b->d_offsets, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
                      p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u);
   HIP_TRY(hipEventRecord(b->ev[1], st));
   // point stages: with the lane-split configuration of the group (Fq2: two lanes per point, Fq3: three) when it has

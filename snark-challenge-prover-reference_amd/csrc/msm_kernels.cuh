@@ -216,8 +216,8 @@ __device__ __forceinline__ uint32_t lds_bits(const uint32_t* sw, int stride, int
 
 template <int FRM>
 __global__ void __launch_bounds__(256) k_scalar_digits(const uint32_t* __restrict__ scal_wire, const uint8_t* __restrict__ inf,
-                                                      int32_t* __restrict__ digits, uint32_t* __restrict__ hist, size_t n,
-                                                      int c, int W, uint32_t hist_stride) {
+                                                      int32_t* __restrict__ digits, uint32_t* __restrict__ rank,
+                                                      uint32_t* __restrict__ hist, size_t n, int c, int W, uint32_t hist_stride) {
   __shared__ uint32_t sw[24 * 256];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int tid = threadIdx.x;
@@ -246,7 +246,10 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint32_t* __restric
       digits[(size_t)w * n + i] = d;
     }
     uint32_t b = d ? (uint32_t)(d < 0 ? -d : d) - 1u : 0u;
-    wave_atomic_inc(hist + (size_t)w * hist_stride, b, d != 0);
+    // the value the histogram atomic returns is the entry's rank inside its bucket: kept, so that the scatter needs no
+    // second round of 38 * N atomics
+    const uint32_t rk = wave_atomic_inc(hist + (size_t)w * hist_stride, b, d != 0);
+    if (d != 0) rank[(size_t)w * n + i] = rk;
   }
 }
 
@@ -340,16 +343,17 @@ static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_finish(uint32_t* _
 // ---- scatter: counting sort of (point, sign) by flattened bucket id ----------------------------
 // hist_stride = 2^(c-1) (one bucket set per window) or 0 (all windows share one bucket set: precomputed tables);
 // the sorted entry is the row index  w * entry_stride + entry_base + i  of the base table, plus the sign bit.
-static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
-                                                uint32_t* __restrict__ sorted, size_t n, int c, int W, uint32_t hist_stride,
-                                                uint32_t entry_stride, uint32_t entry_base) {
+static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, const uint32_t* __restrict__ rank,
+                                                const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, size_t n, int c, int W,
+                                                uint32_t hist_stride, uint32_t entry_stride, uint32_t entry_base) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
+  if (i >= n) return;
   for (int w = 0; w < W; ++w) {
-    int32_t d = live ? digits[(size_t)w * n + i] : 0;
-    uint32_t b = d ? (uint32_t)(d < 0 ? -d : d) - 1u : 0u;
-    uint32_t pos = wave_atomic_inc(cursor + (size_t)w * hist_stride, b, d != 0);
-    if (d != 0) sorted[pos] = ((uint32_t)w * entry_stride + entry_base + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
+    const int32_t d = digits[(size_t)w * n + i];
+    if (d == 0) continue;
+    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+    const uint32_t pos = offsets[(size_t)w * hist_stride + b] + rank[(size_t)w * n + i];   // no atomics: k_scalar_digits kept the rank
+    sorted[pos] = ((uint32_t)w * entry_stride + entry_base + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
   }
 }
 

@@ -28,6 +28,7 @@ struct mnt753_bases {
   size_t ws_n = 0;
   mnt753::MsmPlan ws_plan{};
   int32_t* d_digits = nullptr;
+  uint32_t* d_rank = nullptr;   // rank of every (window, scalar) entry inside its bucket (returned by the histogram atomics)
   uint32_t *d_hist = nullptr, *d_offsets = nullptr, *d_cursor = nullptr, *d_blocksums = nullptr, *d_total = nullptr;
   uint32_t* d_sorted = nullptr;
   uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr, *d_edge_tmp = nullptr, *d_edge_flags = nullptr;
