@@ -593,7 +593,12 @@ __global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict_
   }
 }
 
-// buckets[b] -= fix_count[b] * D for the buckets in which the pairing pass replaced a cancelled pair by D
+template <class C>
+__device__ __forceinline__ int add_pc(Proj<C>& P, const Proj<C>& Q);
+
+// buckets[b] -= fix_count[b] * D for the buckets in which the pairing pass replaced a cancelled pair by D.
+// k * D by double-and-add: an adversarial input (every base next to its negative) can put hundreds of thousands of
+// cancellations into one bucket, and k sequential additions in one lane would take seconds.
 template <class C>
 __global__ void __launch_bounds__(256, 1) k_pair_fix(uint32_t* __restrict__ buckets, const uint32_t* __restrict__ fix_count,
                                                     const uint32_t* __restrict__ gen, uint32_t n_buckets) {
@@ -602,17 +607,20 @@ __global__ void __launch_bounds__(256, 1) k_pair_fix(uint32_t* __restrict__ buck
   if (b >= n_buckets) return;
   const uint32_t k = fix_count[b];
   if (k == 0) return;
-  Proj<C> acc, Q;
-  proj_load<C>(acc, buckets + (size_t)b * proj_words<C>());
+  Proj<C> R, Q;
   e_load<F>(Q.X, gen);
   e_load<F>(Q.Y, gen + F::DEG * FPS_WORDS);
-  F::neg(Q.Y, Q.Y);
+  F::neg(Q.Y, Q.Y);                          // -D
   F::one(Q.Z);
-  for (uint32_t i = 0; i < k; ++i) {
-    int pc = PC_MADD;
-    if (pt_is_zero(acc)) { acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z); pc = PC_END; }
-    pt_vm<C, false>(acc, Q, pc);
+  R = Q;                                     // top bit of k
+  for (int bit = 30 - __clz((int)k); bit >= 0; --bit) {
+    pt_vm<C, true>(R, Q, PC_DBL);
+    if ((k >> bit) & 1u) pt_vm<C, true>(R, Q, pt_is_zero(R) ? PC_END : PC_MADD);
   }
+  Proj<C> acc;
+  proj_load<C>(acc, buckets + (size_t)b * proj_words<C>());
+  const int pc = add_pc<C>(acc, R);
+  pt_vm<C, true>(acc, R, pc);
   proj_store<C>(buckets + (size_t)b * proj_words<C>(), acc);
 }
 

@@ -309,3 +309,19 @@ def test_skewed_scalars_with_the_pairing_pass(gpu, group, logn):
             assert gpu.msm_last_timing()["total_ms"] < 300
     finally:
         bs.close()
+
+
+def test_pairing_pass_thousands_of_cancellations_in_one_bucket(gpu, monkeypatch):
+    """4096 copies of P and 4096 copies of -P under one scalar: every first-level pair of a handful of buckets cancels, so
+    k_pair_fix has to take thousands of stand-ins out of single buckets (k * D by double-and-add, not k additions)."""
+    monkeypatch.setenv("MNT753_MSM_PAIR", "3")
+    n = 8192
+    base = gpu.synth_points(0, 1, 41, 2)
+    s = gpu.synth_scalars(0, 42, 2)
+    pts = np.tile(base[0], (n, 1)); pts[1::2, 12:] = O.neg_fq(0, base[0, 12:])
+    sc = np.tile(s[0], (n, 1))
+    pts[n - 1] = base[1]; sc[n - 1] = s[1]                      # one survivor
+    want = O.msm(0, 1, pts[n - 2:], sc[n - 2:])              # 4096 P - 4095 P = P: P * s0 + base1 * s1
+    got = gpu_msm_affine(gpu, 0, 1, pts, sc)
+    assert np.array_equal(got, want)
+    assert gpu.msm_last_timing()["total_ms"] < 500
