@@ -148,6 +148,14 @@ int mnt753_synth_points(int curve, int group, uint64_t seed, size_t n, uint64_t*
 int mnt753_synth_scalars(int curve, uint64_t seed, size_t n, uint64_t* out_scalars);
 int mnt753_synth_expected_msm(int curve, int group, uint64_t seed, size_t n, const uint64_t* scalars, uint64_t* out_projective);
 
+/* ---- test hooks (tests/ only; not used by the prover) -------------------------------------------------
+ * The device field layer element-wise on n pairs of Fp elements in wire form (host pointers in and out), for known-answer
+ * tests against libff's Fp_model (depends/libff/libff/algebra/fields/fp.tcc:161-186 mul_reduce, :405-417 +=, :491-508 -=,
+ * :641-685 invert, :227-238 as_bigint).  mod: 0 = modulus A (Fr of MNT4753 / Fq of MNT6753), 1 = modulus B.
+ * op: 0 a*b, 1 a+b, 2 a-b, 3 a^-1 (0 -> 0), 4 as_bigint(a), 5 -a, 6 a^2 (dedicated squaring), 7 wire->device->wire,
+ * 8 a*b + a*a (fused two-product multiplier), 9 13*a (small-constant multiplier). */
+int mnt753_test_field_op(int mod, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-#include "fp28_proto.cuh"
+#include "fp28_proto.hip.h"
 #include <cstdio>
 #include <vector>
 // variant B: two accumulators (a*b and m*p chains separate)

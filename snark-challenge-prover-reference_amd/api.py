@@ -69,6 +69,7 @@ def lib():
         "mnt753_synth_points": (i, [i, i, C.c_uint64, sz, u64p, i]),
         "mnt753_synth_scalars": (i, [i, C.c_uint64, sz, u64p]),
         "mnt753_synth_expected_msm": (i, [i, i, C.c_uint64, sz, u64p, u64p]),
+        "mnt753_test_field_op": (i, [i, i, u64p, u64p, sz, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = the library does not export what the header declares
@@ -293,6 +294,15 @@ def synth_expected_msm(curve, group, seed, scalars):
     s, ps = _u64(scalars)
     out = np.zeros(projective_words(curve, group), dtype=np.uint64)
     _check(lib().mnt753_synth_expected_msm(curve, group, seed, s.size // 12, ps, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_synth_expected_msm")
+    return out
+
+
+def test_field_op(mod, op, a, b=None):
+    """Test hook: the device field layer element-wise on wire-form elements (see include/mnt753_hip.h)."""
+    a, pa = _u64(a)
+    b, pb = _u64(a if b is None else b)
+    out = np.zeros_like(a)
+    _check(lib().mnt753_test_field_op(mod, op, pa, pb, a.size // 12, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_field_op")
     return out
 
 

@@ -12,8 +12,8 @@
 // 64 KB instruction cache instead of streaming ~160 KB of straight-line code per addition.
 #pragma once
 #include <type_traits>
-#include "fp753.cuh"
-#include "fp_inv.cuh"
+#include "fp753.hip.h"
+#include "fp_inv.hip.h"
 
 namespace mnt753 {
 

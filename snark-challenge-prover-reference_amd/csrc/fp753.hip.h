@@ -22,7 +22,7 @@
 #include <stdint.h>
 #include "mnt753_constants.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define HD __host__ __device__ __forceinline__
 #else
 #define HD inline
@@ -107,7 +107,7 @@ HD void fp_sqr(Fp<M>& r, const Fp<M>& a) {
 // r = (a1*b1 + a2*b2) * 2^-756 mod p with ONE Montgomery reduction: 2*729 + 729 = 2187 multiply-adds instead of the
 // 2916 of two separate products.  All four inputs in [0, 2p): the sum is < 8p^2, so r < p(8p/R' + 1) < 2p because
 // 8p < 0.89 R' for both moduli (p ~ 1.77 * 2^752).  A column holds at most 54 + 27 products < 2^57 and one carry, well
-// inside 64 bits.  This is the multiplier of the lane-split extension fields (curve753.cuh): every component of a
+// inside 64 bits.  This is the multiplier of the lane-split extension fields (curve753.hip.h): every component of a
 // product in Fq2 is a sum of two base-field products.
 template <int M>
 HD void fp_mul2(Fp<M>& r, const Fp<M>& a1, const Fp<M>& b1, const Fp<M>& a2, const Fp<M>& b2) {

@@ -11,9 +11,9 @@
 // 2^d (Bernstein-Yang 2019, Theorem 11.2); d = 754 gives 2176 <= 78 * 28 = 2184.
 //
 // Representation inside the routine: 27 limbs of 28 bits, limbs 0..25 in [0, 2^28), limb 26 signed -- the same limb width
-// as fp753.cuh, so a 28-step batch divides by exactly one limb.  d and e stay in (-2p, p), f and g in [-p, p].
+// as fp753.hip.h, so a 28-step batch divides by exactly one limb.  d and e stay in (-2p, p), f and g in [-p, p].
 #pragma once
-#include "fp753.cuh"
+#include "fp753.hip.h"
 
 namespace mnt753 {
 

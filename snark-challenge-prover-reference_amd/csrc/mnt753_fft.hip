@@ -7,7 +7,7 @@
 
 #include "common_host.hpp"
 #include "host_field.hpp"
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hip.h"
 
 using namespace mnt753;
 using namespace mnt753::host;

@@ -12,7 +12,7 @@
 #include "../../include/mnt753_hip.h"
 #include "common_host.hpp"
 #include "host_field.hpp"
-#include "msm_kernels.cuh"
+#include "msm_kernels.hip.h"
 #include "msm_types.hpp"
 #include "mnt753_generators.h"
 
@@ -91,11 +91,11 @@ template <class C>
 int proj_w() { return proj_words<C>(); }
 
 // Lane-split point kernels (FieldFp2S / FieldFp3S instantiations): default for the groups that have a split configuration
-// (G2 of both curves); MNT753_MSM_ACC=vm forces the one-lane-per-point kernels, =uniform the wave-uniform XYZZ accumulate.
+// (G2 of both curves); MNT753_MSM_ACC=vm forces the one-lane-per-point kernels.
 template <class C>
 bool use_split_acc() {
   if (std::is_void<typename SplitOf<C>::type>::value) return false;
-  if (const char* e = getenv("MNT753_MSM_ACC")) return strcmp(e, "vm") != 0 && strcmp(e, "uniform") != 0;
+  if (const char* e = getenv("MNT753_MSM_ACC")) return strcmp(e, "vm") != 0;
   return true;
 }
 // threads per point in the point kernels of group C under the current settings
@@ -117,13 +117,12 @@ void free_pair_ws(mnt753_bases* b) {
 
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_rank, b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
-                  b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage, b->d_raw_buckets, b->d_raw_edges, b->d_bucket_state};
+                  b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   free_pair_ws(b);
   if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
   b->d_rank = nullptr; b->d_digits = nullptr; b->d_hist = b->d_offsets = b->d_cursor = b->d_blocksums = b->d_total = nullptr;
   b->d_edge_tmp = b->d_edge_flags = nullptr;
-  b->d_raw_buckets = b->d_raw_edges = nullptr; b->d_bucket_state = nullptr;
   b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
   b->h_wire_out = nullptr; b->d_scalars_stage = nullptr;
   b->ws_n = 0;
@@ -146,9 +145,6 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_buckets, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_edges, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_bucket, sizeof(uint32_t) * 2 * (size_t)p.n_lanes));
-  HIP_TRY(hipMalloc(&b->d_raw_buckets, sizeof(uint32_t) * xyzz_words<C>() * (size_t)p.n_buckets));
-  HIP_TRY(hipMalloc(&b->d_raw_edges, sizeof(uint32_t) * xyzz_words<C>() * 2 * (size_t)p.n_lanes));
-  HIP_TRY(hipMalloc(&b->d_bucket_state, (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_edge_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_flags, sizeof(uint32_t) * 40));
   HIP_TRY(hipMalloc(&b->d_part_a, sizeof(uint32_t) * PW * (size_t)p.n_chunks));
@@ -371,22 +367,10 @@ int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753
   // development: MNT753_SPLIT_MASK selects which kernels run lane-split (bit 0 accumulate, 1 edge sum, 2 bucket reduce, 3 tree)
   unsigned mask = 0xf;
   if (const char* e = getenv("MNT753_SPLIT_MASK")) mask = (unsigned)atoi(e);
-  // accumulate kernel: the lane-divergent projective VM (default: measured faster) or the wave-uniform XYZZ
-  // programs of vm_uniform.cuh (MNT753_MSM_ACC=uniform)
-  bool uniform_acc = false;
-  if (const char* e = getenv("MNT753_MSM_ACC")) uniform_acc = strcmp(e, "uniform") == 0;
-  const int n_pair_levels = (uniform_acc || b->no_pair) ? 0 : pair_levels<V>((uint64_t)p.T * p.n_lanes);
+  const int n_pair_levels = b->no_pair ? 0 : pair_levels<V>((uint64_t)p.T * p.n_lanes);
   uint32_t acc_lanes = p.n_lanes;   // lanes the accumulate kernel ran with (= edge slots / 2)
   g_last_pair_levels = n_pair_levels;
-  if (uniform_acc) {
-    HIP_TRY(hipMemsetAsync(b->d_bucket_state, 0, (size_t)p.n_buckets, st));
-    hipLaunchKernelGGL((k_bucket_accumulate_u<C>), dim3((p.n_lanes + 255) / 256), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
-                       p.n_buckets, b->d_raw_buckets, b->d_raw_edges, b->d_edge_bucket, b->d_bucket_state, p.T, p.n_lanes);
-    hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, b->d_raw_buckets, b->d_buckets,
-                       b->d_bucket_state, (const uint32_t*)nullptr, p.n_buckets);
-    hipLaunchKernelGGL((k_xyzz_to_proj<C>), dim3((2 * p.n_lanes + 255) / 256), dim3(256), 0, st, b->d_raw_edges, b->d_edges,
-                       (const uint8_t*)nullptr, b->d_edge_bucket, 2 * p.n_lanes);
-  } else if (n_pair_levels > 0) {
+  if (n_pair_levels > 0) {
     if (int rc = pair_and_accumulate<V, C>(p, st, d_aff, b, n_pair_levels, &acc_lanes)) return rc;
   } else {
     if (mask & 1u)
@@ -478,7 +462,7 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
                      p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u);
   HIP_TRY(hipEventRecord(b->ev[1], st));
   // point stages: with the lane-split configuration of the group (Fq2: two lanes per point, Fq3: three) when it has
-  // one, otherwise one lane per point.  MNT753_MSM_ACC=vm forces one lane, =uniform the wave-uniform XYZZ accumulate.
+  // one, otherwise one lane per point.  MNT753_MSM_ACC=vm forces one lane.
   uint32_t* cur = nullptr;
   {
     int rc;

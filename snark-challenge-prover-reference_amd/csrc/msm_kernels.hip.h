@@ -20,11 +20,10 @@
 //   k_tree_sum            sums the chunk results
 //   k_points_to_wire      -> wire form (projective, Montgomery R=2^768)
 //   host                  only without the window table (small sets): Horner over the window sums
-// The G2 instantiations of the point kernels run on lane-split extension fields (curve753.cuh): 2 or 3 lanes per point.
+// The G2 instantiations of the point kernels run on lane-split extension fields (curve753.hip.h): 2 or 3 lanes per point.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "curve753.cuh"
-#include "vm_uniform.cuh"
+#include "curve753.hip.h"
 
 namespace mnt753 {
 
@@ -67,7 +66,7 @@ __device__ __forceinline__ void fp_store(uint32_t* p, const Fp<M>& a) {
   }
 }
 // ---- thread -> (logical lane, component) ------------------------------------------------------------------
-// One-lane fields: thread = logical lane.  Lane-split fields (FieldFp2S / FieldFp3S, curve753.cuh): LANES adjacent
+// One-lane fields: thread = logical lane.  Lane-split fields (FieldFp2S / FieldFp3S, curve753.hip.h): LANES adjacent
 // threads form one logical lane and each of them loads / stores only its own component of every element, so the
 // memory layout is identical and split and one-lane kernels can be mixed freely in one pipeline.
 //   LANES = 2: threads (2j, 2j+1);   LANES = 3: lanes (3g, 3g+1, 3g+2) of a wave, lane 63 idles (21 triples per wave).
@@ -438,7 +437,7 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
 // ---- pairing pass: batched affine additions ahead of the accumulate (G1) ------------------------------------
 // The sorted entry list is halved before the projective accumulate: inside every bucket, entries (2j, 2j+1) are added in
 // AFFINE coordinates -- 3 products (lambda, lambda^2, y3) plus 3 for Montgomery's simultaneous-inversion trick plus a
-// 1/B share of one divstep inversion (fp_inv.cuh, ~94 product-equivalents) instead of the 11 of a mixed addition.
+// 1/B share of one divstep inversion (fp_inv.hip.h, ~94 product-equivalents) instead of the 11 of a mixed addition.
 // A lane owns B consecutive OUTPUT slots: forward sweep (running product of the denominators, prefix products to a
 // per-lane HBM workspace), one inversion, backward sweep (individual inverses, the sums).  Output: an affine point array
 // `pairpts` in the row format of the base table, a new entry list `sorted2` (slot -> row, no sign) and the bucket offsets
@@ -624,125 +623,6 @@ __global__ void __launch_bounds__(256, 1) k_pair_fix(uint32_t* __restrict__ buck
   proj_store<C>(buckets + (size_t)b * proj_words<C>(), acc);
 }
 
-// ---- bucket accumulation, wave-uniform version (vm_uniform.cuh) ------------------------------------------
-// Same lane schedule as k_bucket_accumulate (lane t sums sorted entries [t*T, (t+1)*T), whole buckets go to the
-// bucket array, the first / last partial run to the edge slots), but:
-//   * every lane consumes exactly one entry per iteration of a loop whose trip count is T for the whole wave; the
-//     mixed addition is the uniform 13-step XYZZ program with a per-lane commit mask;
-//   * a finished run is written RAW (X, Y, ZZ, ZZZ) with plain stores -- no field arithmetic on the flush path;
-//     k_xyzz_to_proj converts the written slots to homogeneous projective afterwards (3 products per bucket).
-template <class C>
-constexpr int xyzz_words() { return 4 * C::F::DEG * FPS_WORDS; }
-
-template <class C>
-__device__ __forceinline__ void xyzz_store(uint32_t* p, const XyzzAcc<C>& A) {
-  constexpr int EW = C::F::DEG * FPS_WORDS;
-  e_store<typename C::F>(p, A.X);
-  e_store<typename C::F>(p + EW, A.Y);
-  e_store<typename C::F>(p + 2 * EW, A.ZZ);
-  e_store<typename C::F>(p + 3 * EW, A.ZZZ);
-}
-
-template <class C>
-__global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate_u(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                               const uint32_t* __restrict__ offsets, uint32_t n_buckets,
-                                                               uint32_t* __restrict__ raw_buckets, uint32_t* __restrict__ raw_edges,
-                                                               uint32_t* __restrict__ edge_bucket, uint8_t* __restrict__ bucket_state,
-                                                               uint32_t T, uint32_t n_lanes) {
-  using F = typename C::F;
-  using E = typename F::E;
-  constexpr int EW = F::DEG * FPS_WORDS;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_lanes) return;
-  const uint32_t total = offsets[n_buckets];
-  uint64_t e0 = (uint64_t)t * T;
-  if (e0 >= total) {
-    edge_bucket[2 * t] = EDGE_NONE;
-    edge_bucket[2 * t + 1] = EDGE_NONE;
-    return;
-  }
-  uint32_t e = (uint32_t)e0;
-  const uint32_t end = (e0 + T < total) ? (uint32_t)(e0 + T) : total;
-  uint32_t lo = 0, hi = n_buckets;   // first x with offsets[x + 1] > e
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (offsets[mid + 1] > e) hi = mid; else lo = mid + 1;
-  }
-  uint32_t b = lo;
-  uint32_t next = offsets[b + 1];
-  bool first_run = true, acc_zero = true;
-  XyzzAcc<C> acc;
-  E qx, qy;
-  F::zero(acc.X); F::zero(acc.Y); F::zero(acc.ZZ); F::zero(acc.ZZZ);
-  F::zero(qx); F::zero(qy);
-#pragma nounroll
-  for (uint32_t it = 0; it < T; ++it) {
-    const bool live = e < end;
-    if (live && e == next) {
-      // bucket b is complete inside this segment: write it out raw and start the next one
-      if (first_run) {
-        xyzz_store<C>(raw_edges + (size_t)(2 * t) * xyzz_words<C>(), acc);
-        edge_bucket[2 * t] = b;
-        first_run = false;
-      } else {
-        xyzz_store<C>(raw_buckets + (size_t)b * xyzz_words<C>(), acc);
-        bucket_state[b] = 1;
-      }
-      acc_zero = true;
-      do { ++b; next = offsets[b + 1]; } while (next == e);
-    }
-    if (live) {
-      const uint32_t s = sorted[e];
-      const uint32_t* src = bases + (size_t)(s & 0x7fffffffu) * aff_words<C>();
-      e_load<F>(qx, src);
-      e_load<F>(qy, src + EW);
-      if (s & 0x80000000u) F::neg(qy, qy);
-    }
-    const bool start = live && (acc_zero || F::is_zero(acc.ZZ));   // empty accumulator, or a run that summed to the identity
-    if (start) {
-      acc.X = qx; acc.Y = qy; F::one(acc.ZZ); F::one(acc.ZZZ);
-      acc_zero = false;
-    }
-    bool need_dbl;
-    xyzz_madd_uniform<C>(acc, qx, qy, live && !start, need_dbl);
-    if (wave_any(need_dbl)) xyzz_mdbl_uniform<C>(acc, qx, qy, need_dbl);
-    if (live) ++e;
-  }
-  // the last run of the segment is an edge piece
-  if (first_run) {
-    xyzz_store<C>(raw_edges + (size_t)(2 * t) * xyzz_words<C>(), acc);
-    edge_bucket[2 * t] = b;
-    // single-run lane: the second slot is an identity piece (ZZ = 0) of the same bucket: keeps the slot list gap-free
-    F::zero(acc.X); F::zero(acc.Y); F::zero(acc.ZZ); F::zero(acc.ZZZ);
-    xyzz_store<C>(raw_edges + (size_t)(2 * t + 1) * xyzz_words<C>(), acc);
-    edge_bucket[2 * t + 1] = b;
-  } else {
-    xyzz_store<C>(raw_edges + (size_t)(2 * t + 1) * xyzz_words<C>(), acc);
-    edge_bucket[2 * t + 1] = b;
-  }
-}
-
-// raw XYZZ slot j -> homogeneous projective slot j, for the slots marked by state8 (buckets) or ids32 != EDGE_NONE (edges)
-template <class C>
-__global__ void __launch_bounds__(256, 1) k_xyzz_to_proj(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out,
-                                                        const uint8_t* __restrict__ state8, const uint32_t* __restrict__ ids32, uint32_t n) {
-  using F = typename C::F;
-  constexpr int EW = F::DEG * FPS_WORDS;
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const bool on = state8 ? (state8[j] != 0) : (ids32[j] != EDGE_NONE);
-  if (!wave_any(on)) return;
-  XyzzAcc<C> A;
-  F::zero(A.X); F::zero(A.Y); F::zero(A.ZZ); F::zero(A.ZZZ);
-  if (on) {
-    const uint32_t* p = raw + (size_t)j * xyzz_words<C>();
-    e_load<F>(A.X, p); e_load<F>(A.Y, p + EW); e_load<F>(A.ZZ, p + 2 * EW); e_load<F>(A.ZZZ, p + 3 * EW);
-  }
-  Proj<C> P;
-  xyzz_to_proj_uniform<C>(P, A);
-  if (on) proj_store<C>(out + (size_t)j * proj_words<C>(), P);
-}
-
 // full projective addition with identity handling, through the VM
 template <class C>
 __device__ __forceinline__ int add_pc(Proj<C>& P, const Proj<C>& Q) {
@@ -916,27 +796,6 @@ __global__ void __launch_bounds__(64) k_points_to_wire(const uint32_t* __restric
 // SAME bucket set (sum_w d_w * (2^(cw) P) = s * P), so one MSM needs W*N bucket additions into 2^(c-1) buckets,
 // ONE bucket reduction instead of W, and no Horner pass.  Built once per base set, at parameter-load time
 // (the reference's timing window opens after the parameters are loaded, libsnark/main.cpp:201-203).
-// (kept as the cross-check of fp_inv in tools/dev_inv_gpu.hip; the product path uses the divstep inversion of fp_inv.cuh)
-template <int M>
-__device__ void fp_inv_fermat(Fp<M>& r, const Fp<M>& x) {
-  // x^(p-2), exponent limbs from the constants table
-  Fp<M> acc, a, b, t;
-  fp_one(acc);
-  bool started = false;
-#pragma unroll 1
-  for (int i = NL * LB - 1; i >= 0; --i) {
-    const uint32_t limb = FPC[M].pm2[i / LB];
-    const bool bit = (limb >> (i % LB)) & 1u;
-#pragma unroll 1
-    for (int phase = 0; phase < 2; ++phase) {
-      if (phase == 0) { if (!started) continue; a = acc; b = acc; }
-      else { if (!bit) continue; a = acc; b = x; started = true; }
-      fp_mul(t, a, b);
-      acc = t;
-    }
-  }
-  r = acc;
-}
 template <int M>
 __device__ void e_inv(Fp<M>& r, const Fp<M>& a, FieldFp<M>*) { fp_inv(r, a); }
 template <int M, unsigned NR>

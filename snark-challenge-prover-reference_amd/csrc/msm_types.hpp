@@ -33,8 +33,6 @@ struct mnt753_bases {
   uint32_t* d_sorted = nullptr;
   uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr, *d_edge_tmp = nullptr, *d_edge_flags = nullptr;
   uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;
-  uint32_t *d_raw_buckets = nullptr, *d_raw_edges = nullptr;   // XYZZ slots of the wave-uniform accumulate kernel
-  uint8_t* d_bucket_state = nullptr;
   // pairing pass (batched affine additions ahead of the accumulate, MNT753_MSM_PAIR=1): allocated on first use
   uint32_t *d_cnt2 = nullptr, *d_pair_ws = nullptr, *d_fix = nullptr, *d_gen = nullptr;
   uint32_t *d_offsets2[2] = {nullptr, nullptr}, *d_pairpts[2] = {nullptr, nullptr}, *d_sorted2[2] = {nullptr, nullptr};   // ping-pong over the levels

@@ -16,8 +16,8 @@
 //   * the libfqfft scale loops (1/m, g^i, g^-i, 1/Z) are table multiplies fused pairwise.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "fp753.cuh"
-#include "msm_kernels.cuh"   // storage helpers (fp_load / fp_store / load_wire24 / store_wire24)
+#include "fp753.hip.h"
+#include "msm_kernels.hip.h"   // storage helpers (fp_load / fp_store / load_wire24 / store_wire24)
 
 namespace mnt753 {
 

@@ -3,6 +3,8 @@
 // here every vector lives in HBM and every heavy call is a HIP kernel launch.
 #include "../../include/prover_hip_functions.hpp"
 
+#include <sys/stat.h>
+
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -92,6 +94,21 @@ public:
     read_exact(f, dm, 16, path);
     d = dm[0]; m = dm[1];
     const size_t g1w = mnt753_affine_words(CURVE, MNT753_G1), g2w = mnt753_affine_words(CURVE, MNT753_G2);
+    // The reference trusts d and m (prover_reference_functions.cpp:86-116); here they size device allocations, so they
+    // are checked against the file before anything is allocated: 16 + 8*(g1w*(3m + d + 1) + g2w*(m + 1)) bytes exactly.
+    {
+      struct stat st;
+      if (m < 2 || d < 1 || m > ((size_t)1 << 31) || d > ((size_t)1 << 31) || stat(path, &st) != 0) {
+        fclose(f);
+        throw std::runtime_error(std::string("bad params header (d, m) in ") + path);
+      }
+      const unsigned long long expect = 16ull + 8ull * ((unsigned long long)g1w * (3ull * m + d + 1ull) + (unsigned long long)g2w * (m + 1ull));
+      if ((unsigned long long)st.st_size != expect) {
+        fclose(f);
+        throw std::runtime_error(std::string("params file size does not match its header (d=") + std::to_string(d) + ", m=" + std::to_string(m) +
+                                 ", expected " + std::to_string(expect) + " bytes, found " + std::to_string((unsigned long long)st.st_size) + "): " + path);
+      }
+    }
     auto load = [&](int group, size_t words, size_t n) {
       std::vector<uint64_t> host(words * n);
       read_exact(f, host.data(), host.size() * 8, path);
@@ -124,6 +141,13 @@ public:
     if (!f) throw std::runtime_error(std::string("cannot open input file ") + path);
     n_w = m + 1; n_c = d + 1;
     const size_t r_off = 96 * (n_w + 3 * n_c);
+    {
+      struct stat st;
+      if (stat(path, &st) != 0 || (unsigned long long)st.st_size != (unsigned long long)r_off + 96ull) {
+        fclose(f);
+        throw std::runtime_error(std::string("input file size does not match the parameters (expected ") + std::to_string(r_off + 96) + " bytes): " + path);
+      }
+    }
     if (fseeko(f, (off_t)r_off, SEEK_SET) != 0 || fread(r, 1, 96, f) != 96) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
     fclose(f);
     w = std::make_shared<DeviceBuffer>(96 * n_w);

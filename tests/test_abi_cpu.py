@@ -110,7 +110,7 @@ def test_synthetic_inputs(pkg, curve, group):
 
 
 def test_device_field_arithmetic_compiled_for_the_host(tmp_path):
-    """fp753.cuh is __host__ __device__: the fused multipliers of the lane-split extension fields (fp_mul2, fp_mul3) and
+    """fp753.hip.h is __host__ __device__: the fused multipliers of the lane-split extension fields (fp_mul2, fp_mul3) and
     the dedicated squaring (fp_sqr) must agree with compositions of the plain Montgomery product fp_mul -- which the
     oracle-pinned GPU parity tests cover -- and keep their results in [0, 2p).  2000 random cases per modulus."""
     import subprocess

@@ -1,11 +1,35 @@
-// Development microbenchmark (GPU box): divstep inversion (fp_inv.cuh) vs the Fermat chain, one element per lane,
+// Development microbenchmark (GPU box): divstep inversion (fp_inv.hip.h) vs the Fermat chain, one element per lane,
 // one wave per SIMD over the whole chip.  Checks x * x^-1 = 1 and that both routines agree, then times each.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/dev_inv_gpu.hip -o build/dev_inv_gpu && ./build/dev_inv_gpu
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../snark-challenge-prover-reference_amd/csrc/msm_kernels.cuh"
+#include "../snark-challenge-prover-reference_amd/csrc/msm_kernels.hip.h"
 using namespace mnt753;
+
+namespace mnt753 {
+// Fermat chain x^(p-2): the cross-check of the divstep inversion (moved here from the product in round 2)
+template <int M>
+__device__ void fp_inv_fermat(Fp<M>& r, const Fp<M>& x) {
+  // x^(p-2), exponent limbs from the constants table
+  Fp<M> acc, a, b, t;
+  fp_one(acc);
+  bool started = false;
+#pragma unroll 1
+  for (int i = NL * LB - 1; i >= 0; --i) {
+    const uint32_t limb = FPC[M].pm2[i / LB];
+    const bool bit = (limb >> (i % LB)) & 1u;
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+      if (phase == 0) { if (!started) continue; a = acc; b = acc; }
+      else { if (!bit) continue; a = acc; b = x; started = true; }
+      fp_mul(t, a, b);
+      acc = t;
+    }
+  }
+  r = acc;
+}
+}  // namespace mnt753
 
 template <int M>
 __global__ void __launch_bounds__(256, 1) k_make(uint32_t* x, int n) {

@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "../snark-challenge-prover-reference_amd/csrc/msm_kernels.cuh"
+#include "../snark-challenge-prover-reference_amd/csrc/msm_kernels.hip.h"
 #include "../snark-challenge-prover-reference_amd/csrc/host_field.hpp"
 using namespace mnt753;
 

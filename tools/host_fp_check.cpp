@@ -1,7 +1,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
-#include "../snark-challenge-prover-reference_amd/csrc/fp_inv.cuh"   // host build: g++ -O1 -std=c++17 tools/host_fp_check.cpp
+#include "../snark-challenge-prover-reference_amd/csrc/fp_inv.hip.h"   // host build: g++ -O1 -std=c++17 tools/host_fp_check.cpp
 using namespace mnt753;
 static uint64_t st = 88172645463325252ull;
 static uint64_t rnd() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; }

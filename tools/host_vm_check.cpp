@@ -1,9 +1,9 @@
-// Development harness: runs the device point-operation VMs (curve753.cuh is __host__ __device__) on the CPU
+// Development harness: runs the device point-operation VMs (curve753.hip.h is __host__ __device__) on the CPU
 // against the reference's golden group vectors.  Build: hipcc -O1 -std=c++17 tools/host_vm_check.cpp -o build/host_vm_check
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "../snark-challenge-prover-reference_amd/csrc/vm_uniform.cuh"
+#include "experiments/vm_uniform.hip.h"
 #include "../snark-challenge-prover-reference_amd/csrc/host_field.hpp"
 using namespace mnt753;
 

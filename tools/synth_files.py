@@ -10,8 +10,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+DEFAULT_SEED = 0x6d696e61   # SURVEY.md section 8d; tests/golden/oracle_hashes.json records the reference's proofs for this seed
 
-def write_files(pkg, curve, log2_d, params_path, input_path, seed=0x6d696e61):
+
+def write_files(pkg, curve, log2_d, params_path, input_path, seed=DEFAULT_SEED):
     d = (1 << log2_d) - 1
     m = d + 1
     with open(params_path, "wb") as f:
