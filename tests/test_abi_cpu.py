@@ -119,3 +119,19 @@ def test_device_field_arithmetic_compiled_for_the_host(tmp_path):
     subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), src], check=True, timeout=600)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/cuda_prover_piecewise.cu"), reason="needs the reference tree (build container only)")
+def test_reference_driver_compiles_unchanged_against_the_hip_wrapper(tmp_path):
+    """The drop-in claim of include/prover_hip_functions.hpp: compute_H<B>, run_prover<B> and main of the reference's
+    cuda_prover_piecewise.cu (lines 14-120, untouched) compile and link with B = mnt4753_hip / mnt6753_hip -- only the two
+    instantiations and the include line change (tools/dropin_check.sh verifies that nothing else differs)."""
+    r = subprocess.run(["sh", os.path.join(ROOT, "tools", "dropin_check.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = os.path.join(ROOT, "oracle", "_ref", "piecewise_hip")
+    assert os.access(exe, os.X_OK)
+    if not has_gpu():
+        # the reference's driver has no error handling of its own: without a device the wrapper's exception ends the process
+        params, inp, _ = G.e2e_paths(0)
+        p = subprocess.run([exe, "MNT4753", "compute", params, inp, str(tmp_path / "o")], capture_output=True, text=True)
+        assert p.returncode != 0 and "no HIP device" in p.stderr

@@ -64,6 +64,32 @@ def test_multi_gpu_driver_reference_proofs(gpu, curve, world, tmp_path):
     assert '"total_input_to_output_s"' in r.stdout
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+def test_reference_driver_unchanged(gpu, curve, tmp_path):
+    """oracle/_ref/piecewise_hip = the reference's own cuda_prover_piecewise.cu driver (lines 14-120, untouched) compiled over
+    include/prover_hip_functions.hpp by tools/dropin_check.sh in the build container: same proof bytes as the reference."""
+    exe = os.path.join(O.ROOT, "oracle", "_ref", "piecewise_hip")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/piecewise_hip not built (tools/dropin_check.sh needs the reference tree)")
+    params, inp, expected = G.e2e_paths(curve)
+    out = str(tmp_path / "proof.bin")
+    r = subprocess.run([exe, NAME[curve], "compute", params, inp, out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(out, expected, shallow=False)
+
+
+def test_params_header_is_validated(gpu, tmp_path):
+    params, inp, _ = G.e2e_paths(0)
+    raw = bytearray(open(params, "rb").read())
+    raw[8:16] = (1 << 40).to_bytes(8, "little")          # m = 2^40
+    bad = tmp_path / "params_bad"; bad.write_bytes(raw)
+    r = subprocess.run([EXE, "MNT4753", "compute", str(bad), inp, str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 1 and ("bad params header" in r.stderr or "does not match" in r.stderr)
+    trunc = tmp_path / "params_trunc"; trunc.write_bytes(bytes(raw[:-8]))
+    r = subprocess.run([EXE, "MNT4753", "compute", str(trunc), inp, str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 1
+
+
 def test_cli_errors(gpu, tmp_path):
     r = subprocess.run([EXE, "MNT4753", "compute", "/nonexistent", "/nonexistent", str(tmp_path / "o")], capture_output=True, text=True)
     assert r.returncode == 1 and "cannot open" in r.stderr
