@@ -79,6 +79,7 @@ MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   if (const char* e = getenv("MNT753_MSM_L")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v <= p.nb && (v & (v - 1)) == 0) L = v; }
   p.L = L;
   p.n_chunks = p.n_buckets / L;
+  p.pair_levels = 0;   // filled in by the caller (plan_for): depends on the group and on the workspace the base set could get
   return p;
 }
 
@@ -106,11 +107,11 @@ int point_lanes() {
   else return use_split_acc<C>() ? CS::F::LANES : 1;
 }
 void free_pair_ws(mnt753_bases* b) {
-  void* ptrs[] = {b->d_cnt2, b->d_pair_ws, b->d_fix, b->d_gen, b->d_offsets2[0], b->d_offsets2[1], b->d_pairpts[0], b->d_pairpts[1],
-                  b->d_sorted2[0], b->d_sorted2[1]};
+  void* ptrs[] = {b->d_pair_ws, b->d_fix, b->d_gen, b->d_pair_kind, b->d_pairpts[0], b->d_pairpts[1], b->d_sorted2};
   for (void* q : ptrs) if (q) (void)hipFree(q);
-  b->d_cnt2 = b->d_pair_ws = b->d_fix = b->d_gen = nullptr;
-  for (int k = 0; k < 2; ++k) b->d_offsets2[k] = b->d_pairpts[k] = b->d_sorted2[k] = nullptr;
+  b->d_pair_ws = b->d_fix = b->d_gen = b->d_sorted2 = nullptr;
+  b->d_pair_kind = nullptr;
+  b->d_pairpts[0] = b->d_pairpts[1] = nullptr;
   b->pair_cap = 0;
   b->pair_buckets = 0;
 }
@@ -126,11 +127,15 @@ void free_ws(mnt753_bases* b) {
   b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
   b->h_wire_out = nullptr; b->d_scalars_stage = nullptr;
   b->ws_n = 0;
+  b->sorted_cap = 0;
 }
 
 template <class C>
 int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
-  if (b->ws_n >= n && b->ws_plan.c == p.c && b->ws_plan.pre == p.pre && b->ws_plan.T == p.T && b->ws_plan.L == p.L && b->ws_plan.n_lanes >= p.n_lanes) return 0;
+  // entries of the sorted list: every bucket padded to a multiple of 2^pair_levels
+  const size_t sorted_need = (size_t)p.W * n + (size_t)p.n_buckets * (((size_t)1 << p.pair_levels) - 1);
+  if (b->ws_n >= n && b->ws_plan.c == p.c && b->ws_plan.pre == p.pre && b->ws_plan.T == p.T && b->ws_plan.L == p.L && b->ws_plan.n_lanes >= p.n_lanes &&
+      b->sorted_cap >= sorted_need) return 0;
   free_ws(b);
   const size_t PW = proj_words<C>();
   const size_t nscan_blocks = ((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -141,7 +146,8 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_cursor, sizeof(uint32_t) * (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_blocksums, sizeof(uint32_t) * (nscan_blocks + 1)));
   HIP_TRY(hipMalloc(&b->d_total, sizeof(uint32_t) * 4));
-  HIP_TRY(hipMalloc(&b->d_sorted, sizeof(uint32_t) * (size_t)p.W * n));
+  HIP_TRY(hipMalloc(&b->d_sorted, sizeof(uint32_t) * sorted_need));
+  b->sorted_cap = sorted_need;
   HIP_TRY(hipMalloc(&b->d_buckets, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_edges, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_bucket, sizeof(uint32_t) * 2 * (size_t)p.n_lanes));
@@ -158,10 +164,8 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   return 0;
 }
 
-template <class V> int pair_levels(uint64_t entries);
-template <class C> int pair_levels_for(uint64_t entries);
-template <class C> int ensure_pair_ws_for(mnt753_bases* b, const MsmPlan& p);
-template <class V, class C> int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p);
+template <class C> MsmPlan plan_for(const mnt753_bases* b, size_t n);
+template <class C> int ensure_pair_ws_for(mnt753_bases* b, const MsmPlan& p, size_t n);
 
 template <class C>
 int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_t n) {
@@ -210,14 +214,15 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   // Workspace and events of a full-size MSM over this set are allocated here, at parameter-load time, so that the
   // first mnt753_msm* call on the set does not start with ~20 hipMallocs.
   {
-    MsmPlan p = make_plan(n, b->pre_c, point_lanes<C>());
-    if (int rc = ensure_ws<C>(b, n, p)) return rc;
-    if (pair_levels_for<C>((uint64_t)p.T * p.n_lanes) > 0 && ensure_pair_ws_for<C>(b, p) != 0) {
-      // not enough HBM for the pairing buffers (~7 GB per 2^20 G1 points): keep the set usable without the pairing pass
+    MsmPlan p = plan_for<C>(b, n);
+    if (p.pair_levels > 0 && ensure_pair_ws_for<C>(b, p, n) != 0) {
+      // not enough HBM for the pairing buffers (~7 GB per 2^20 G1 points): keep the set usable without the pairing levels
       free_pair_ws(b);
       b->no_pair = 1;
       (void)hipGetLastError();
+      p = plan_for<C>(b, n);
     }
+    if (int rc = ensure_ws<C>(b, n, p)) return rc;
     for (int i = 0; i < 5; ++i)
       if (!b->ev[i]) HIP_TRY(hipEventCreate(&b->ev[i]));
   }
@@ -237,9 +242,9 @@ void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
   acc.to_wire(out);
 }
 
-// Pairing passes (k_pair_add, MNT753_MSM_PAIR = number of levels) + accumulate over the shortened list; base-field groups.
-// lanes per pairing level (two rounds of the machine at two waves per SIMD) and minimum additions per inversion (keeps its
-// share below one product per addition); MNT753_PAIR_LANES / MNT753_PAIR_MINB are development overrides
+// Pairing levels (k_pair_level, MNT753_MSM_PAIR = number of levels) + accumulate over the shortened list.
+// Lanes per level: two rounds of the machine at two waves per SIMD; minimum additions per inversion: keeps its share below one
+// product per addition.  MNT753_PAIR_LANES / MNT753_PAIR_MINB are development overrides.
 inline uint32_t pair_env(const char* name, uint32_t dflt) { const char* e = getenv(name); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; }
 #define PAIR_MAX_LANES pair_env("MNT753_PAIR_LANES", 131072u)
 #define PAIR_MIN_B pair_env("MNT753_PAIR_MINB", 48u)
@@ -261,56 +266,51 @@ int pair_levels(uint64_t entries) {
     return 0;
   }
 }
-// buffers of the pairing passes for an MSM with plan p (allocated with the base set when MNT753_MSM_PAIR is set)
+// level-1 slots of the worst case of plan p: (W n + n_buckets (2^L - 1)) / 2
+inline uint64_t pair_cap1(const MsmPlan& p, size_t n) {
+  return ((uint64_t)p.W * n + (uint64_t)p.n_buckets * (((uint64_t)1 << p.pair_levels) - 1)) / 2;
+}
+// buffers of the pairing levels for an MSM over n points with plan p; grow only
 template <class V, class C>
-int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p) {
+int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p, size_t n) {
   if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
-    const uint64_t entries = (uint64_t)p.T * p.n_lanes;
-    const uint64_t cap1 = (entries + p.n_buckets) / 2 + 2;
-    const uint32_t max_lanes = PAIR_MAX_LANES / (uint32_t)V::F::LANES;   // logical lanes
-    const uint32_t min_B = PAIR_MIN_B;
+    const uint64_t cap1 = pair_cap1(p, n);
     if (b->pair_cap >= cap1 && b->pair_buckets >= p.n_buckets) return 0;
-    {
-      // grow only: keep room for the largest plan this base set has run with
-      const uint64_t capA = std::max<uint64_t>(cap1, b->pair_cap);
-      const size_t nbA = std::max<size_t>(p.n_buckets, b->pair_buckets);
-      free_pair_ws(b);
-      const uint64_t cap2 = (capA + nbA) / 2 + 2;
-      HIP_TRY(hipMalloc(&b->d_cnt2, sizeof(uint32_t) * (nbA + 1)));
-      HIP_TRY(hipMalloc(&b->d_fix, sizeof(uint32_t) * nbA));
-      HIP_TRY(hipMalloc(&b->d_gen, sizeof(uint32_t) * aff_words<V>()));
-      for (int k = 0; k < 2; ++k) {
-        const uint64_t cap = k == 0 ? capA : cap2;
-        HIP_TRY(hipMalloc(&b->d_offsets2[k], sizeof(uint32_t) * (nbA + 1)));
-        HIP_TRY(hipMalloc(&b->d_pairpts[k], sizeof(uint32_t) * aff_words<V>() * cap));
-        HIP_TRY(hipMalloc(&b->d_sorted2[k], sizeof(uint32_t) * cap));
-      }
-      const uint64_t B1 = std::max<uint64_t>((capA + max_lanes - 1) / max_lanes, min_B);
-      HIP_TRY(hipMalloc(&b->d_pair_ws, sizeof(uint32_t) * FPS_WORDS * V::F::DEG * (size_t)(B1 + 1) * max_lanes));
-      // D: the group generator in device form (wire constant -> k_bases_to_internal)
-      uint32_t* wire = nullptr; uint8_t* inf = nullptr;
-      const size_t gen_bytes = 192 * (size_t)C::F::DEG;
-      const uint64_t* gen_wire = b->curve == MNT753_CURVE_MNT4753 ? (C::F::DEG == 1 ? GEN_MNT4_G1 : GEN_MNT4_G2) : (C::F::DEG == 1 ? GEN_MNT6_G1 : GEN_MNT6_G2);
-      HIP_TRY(hipMalloc(&wire, gen_bytes)); HIP_TRY(hipMalloc(&inf, 16));
-      HIP_TRY(hipMemcpy(wire, gen_wire, gen_bytes, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL((k_bases_to_internal<C>), dim3(1), dim3(256), 0, 0, wire, b->d_gen, inf, (size_t)1);
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(wire)); HIP_TRY(hipFree(inf));
-      b->pair_cap = capA;
-      b->pair_buckets = nbA;
-    }
+    const uint64_t capA = std::max<uint64_t>(cap1, b->pair_cap);
+    const size_t nbA = std::max<size_t>(p.n_buckets, b->pair_buckets);
+    free_pair_ws(b);
+    HIP_TRY(hipMalloc(&b->d_fix, sizeof(uint32_t) * nbA));
+    HIP_TRY(hipMalloc(&b->d_gen, sizeof(uint32_t) * aff_words<V>()));
+    // rows of a level: row-major (last level, 224 B x DEG per slot) or four blocked planes (same bytes + rounding per plane)
+    const size_t slack = 4 * 64 * 7 * 16 * 2;
+    HIP_TRY(hipMalloc(&b->d_pairpts[0], sizeof(uint32_t) * aff_words<V>() * capA + slack * V::F::DEG));             // levels 1, 3, 5
+    HIP_TRY(hipMalloc(&b->d_pairpts[1], sizeof(uint32_t) * aff_words<V>() * (capA / 2 + 1) + slack * V::F::DEG));   // levels 2, 4, 6
+    HIP_TRY(hipMalloc(&b->d_sorted2, sizeof(uint32_t) * capA));                                 // entry list of the last level
+    HIP_TRY(hipMalloc(&b->d_pair_ws, 16 * blk_quads((uint64_t)capA * V::F::LANES + 64)));       // one prefix product per slot (blocked)
+    HIP_TRY(hipMalloc(&b->d_pair_kind, (size_t)capA * V::F::LANES));
+    // D: the group generator in device form (wire constant -> k_bases_to_internal)
+    uint32_t* wire = nullptr; uint8_t* inf = nullptr;
+    const size_t gen_bytes = 192 * (size_t)C::F::DEG;
+    const uint64_t* gen_wire = b->curve == MNT753_CURVE_MNT4753 ? (C::F::DEG == 1 ? GEN_MNT4_G1 : GEN_MNT4_G2) : (C::F::DEG == 1 ? GEN_MNT6_G1 : GEN_MNT6_G2);
+    HIP_TRY(hipMalloc(&wire, gen_bytes)); HIP_TRY(hipMalloc(&inf, 16));
+    HIP_TRY(hipMemcpy(wire, gen_wire, gen_bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_bases_to_internal<C>), dim3(1), dim3(256), 0, 0, wire, b->d_gen, inf, (size_t)1);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(wire)); HIP_TRY(hipFree(inf));
+    b->pair_cap = capA;
+    b->pair_buckets = nbA;
     return 0;
   } else {
-    (void)b; (void)p;
+    (void)b; (void)p; (void)n;
     return 0;
   }
 }
 // workspace for the configuration the point kernels of group C currently run with
 template <class C>
-int ensure_pair_ws_for(mnt753_bases* b, const MsmPlan& p) {
+int ensure_pair_ws_for(mnt753_bases* b, const MsmPlan& p, size_t n) {
   using CS = typename SplitOf<C>::type;
-  if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return ensure_pair_ws<CS, C>(b, p); }
-  return ensure_pair_ws<C, C>(b, p);
+  if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return ensure_pair_ws<CS, C>(b, p, n); }
+  return ensure_pair_ws<C, C>(b, p, n);
 }
 template <class C>
 int pair_levels_for(uint64_t entries) {
@@ -318,44 +318,66 @@ int pair_levels_for(uint64_t entries) {
   if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return pair_levels<CS>(entries); }
   return pair_levels<C>(entries);
 }
+// plan of an MSM over n points of base set b: make_plan + the pairing levels this group / base set runs with
+template <class C>
+MsmPlan plan_for(const mnt753_bases* b, size_t n) {
+  MsmPlan p = make_plan(n, b->pre_c, point_lanes<C>());
+  p.pair_levels = b->no_pair ? 0 : pair_levels_for<C>((uint64_t)p.W * n);
+  // the padded list must keep 32-bit slot indices
+  while (p.pair_levels > 0 && (uint64_t)p.W * n + (uint64_t)p.n_buckets * (((uint64_t)1 << p.pair_levels) - 1) >= 0xfffffff0ull) --p.pair_levels;
+  return p;
+}
 template <class V, class C>
-int pair_and_accumulate(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, int levels, uint32_t* acc_lanes) {
+int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, uint32_t* acc_lanes) {
   if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
-    const uint64_t entries = (uint64_t)p.T * p.n_lanes;                       // upper bound of the sorted entries
-    const uint64_t cap1 = (entries + p.n_buckets) / 2 + 2;                    // sum over the buckets of ceil(count / 2)
+    const int levels = p.pair_levels;
     const uint32_t max_lanes = PAIR_MAX_LANES / (uint32_t)V::F::LANES;   // logical lanes
     const uint32_t min_B = PAIR_MIN_B;
-    if (int rc = ensure_pair_ws<V, C>(b, p)) return rc;
+    if (int rc = ensure_pair_ws<V, C>(b, p, n)) return rc;
     HIP_TRY(hipMemsetAsync(b->d_fix, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
-    const uint32_t* cur_table = d_aff;
-    const uint32_t* cur_sorted = b->d_sorted;
-    const uint32_t* cur_offsets = b->d_offsets;
-    uint64_t cap = entries;
-    const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    for (int l = 0; l < levels; ++l) {
-      const int k = l & 1;
-      cap = (cap + p.n_buckets) / 2 + 2;
-      // worst-case batch length (the workspace is sized for it); the kernel shortens it to the actual slot count
-      const uint32_t B = (uint32_t)std::max<uint64_t>((cap + max_lanes - 1) / max_lanes, min_B);
-      const uint32_t lanes = (uint32_t)((cap + B - 1) / B);
-      hipLaunchKernelGGL(k_pair_counts, dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, cur_offsets, b->d_cnt2, p.n_buckets);
-      hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_cnt2, b->d_offsets2[k], b->d_blocksums, (size_t)p.n_buckets);
-      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
-      hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets2[k], b->d_cnt2, b->d_blocksums, b->d_total,
-                         (size_t)p.n_buckets);
-      hipLaunchKernelGGL((k_pair_add<V>), dim3(blocks_for<typename V::F>(lanes)), dim3(256), 0, st, cur_table, cur_sorted, cur_offsets, b->d_offsets2[k],
-                         p.n_buckets, b->d_pairpts[k], b->d_sorted2[k], b->d_pair_ws, min_B, lanes, b->d_gen, b->d_fix);
-      cur_table = b->d_pairpts[k]; cur_sorted = b->d_sorted2[k]; cur_offsets = b->d_offsets2[k];
+    uint64_t cap = 2 * pair_cap1(p, n);        // worst-case entries of the padded list
+    const uint4* src_planes = nullptr;
+    size_t src_stride = 0;
+    const uint32_t* last_rows = nullptr;
+    for (int l = 1; l <= levels; ++l) {
+      cap /= 2;                                 // worst-case slots of this level (the kernel reads the actual count from offsG)
+      const uint32_t lanes = (uint32_t)std::min<uint64_t>(max_lanes, (cap + min_B - 1) / min_B);
+      uint32_t* out = b->d_pairpts[(l - 1) & 1];
+      const int first = l == 1, last = l == levels;
+      // planes of a level that feeds another one: (x | y) x (even | odd slot), each holding cap / 2 slots, blocked
+      const size_t out_stride = blk_quads((cap / 2 + 1) * (uint64_t)V::F::LANES + 64);
+#define MNT753_PAIR_LAUNCH(FST, LST)                                                                                                         \
+  hipLaunchKernelGGL((k_pair_level<V, FST, LST>), dim3(blocks_for<typename V::F>(lanes)), dim3(256), 0, st, d_aff, b->d_sorted, src_planes, src_stride, \
+                     b->d_offsets, p.n_buckets, (uint32_t)(levels - l), out, b->d_sorted2, reinterpret_cast<uint4*>(out), out_stride,              \
+                     reinterpret_cast<uint4*>(b->d_pair_ws), b->d_pair_kind, min_B, lanes, b->d_gen, b->d_fix, pair_env("MNT753_PAIR_DBG", 0u))
+      if (first && last) MNT753_PAIR_LAUNCH(true, true);
+      else if (first) MNT753_PAIR_LAUNCH(true, false);
+      else if (last) MNT753_PAIR_LAUNCH(false, true);
+      else MNT753_PAIR_LAUNCH(false, false);
+#undef MNT753_PAIR_LAUNCH
+      src_planes = reinterpret_cast<const uint4*>(out);
+      src_stride = out_stride;
+      last_rows = out;
+#ifdef MNT753_PAIR_TIMING
+      {
+        unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pair_cycles), sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_cycles), z, sizeof(z));
+        if (h[3]) fprintf(stderr, "pair level %d: waves %llu  cycles/wave: forward %.0f  inversion %.0f  backward %.0f (wait+sub %.0f, steps %.0f)\n", l, h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[6] / h[3], (double)h[5] / h[3]);
+      }
+#endif
     }
+    const uint32_t* src = last_rows;
     // accumulate over at most `cap` entries: one round of the machine
     const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, V::F::LANES == 3 ? 21504u : 65536u / (uint32_t)V::F::LANES);
     const uint32_t T2 = (uint32_t)std::max<uint64_t>((cap + lanes_acc - 1) / lanes_acc, 8);
-    hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, cur_table, cur_sorted,
-                       cur_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc);
+    hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, src, b->d_sorted2,
+                       b->d_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc);
     *acc_lanes = lanes_acc;
     return 0;
   } else {
-    (void)p; (void)st; (void)d_aff; (void)b; (void)levels; (void)acc_lanes;
+    (void)p; (void)n; (void)st; (void)d_aff; (void)b; (void)acc_lanes;
     return 0;
   }
 }
@@ -363,15 +385,15 @@ int pair_and_accumulate(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff,
 // The stages that run point arithmetic.  V = the configuration the point-operation VM is instantiated with (C itself,
 // or its lane-split counterpart); kernels that only move points are layout-agnostic and use C.
 template <class V, class C>
-int point_stages(const MsmPlan& p, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, uint32_t** result) {
+int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, uint32_t** result) {
   // development: MNT753_SPLIT_MASK selects which kernels run lane-split (bit 0 accumulate, 1 edge sum, 2 bucket reduce, 3 tree)
   unsigned mask = 0xf;
   if (const char* e = getenv("MNT753_SPLIT_MASK")) mask = (unsigned)atoi(e);
-  const int n_pair_levels = b->no_pair ? 0 : pair_levels<V>((uint64_t)p.T * p.n_lanes);
+  const int n_pair_levels = p.pair_levels;
   uint32_t acc_lanes = p.n_lanes;   // lanes the accumulate kernel ran with (= edge slots / 2)
   g_last_pair_levels = n_pair_levels;
   if (n_pair_levels > 0) {
-    if (int rc = pair_and_accumulate<V, C>(p, st, d_aff, b, n_pair_levels, &acc_lanes)) return rc;
+    if (int rc = pair_and_accumulate<V, C>(p, n, st, d_aff, b, &acc_lanes)) return rc;
   } else {
     if (mask & 1u)
       hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
@@ -434,7 +456,14 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   if (b->pending) return set_error(MNT753_EINVAL, "msm_start: this base set already has an MSM in flight (finish it first)");
   b->pending = 1; b->pending_n = n; b->pending_stream = st;
   if (n == 0) return 0;
-  MsmPlan p = make_plan(n, b->pre_c, point_lanes<C>());
+  MsmPlan p = plan_for<C>(b, n);
+  if (p.pair_levels > 0 && ensure_pair_ws_for<C>(b, p, n) != 0) {
+    // the pairing buffers do not fit (a larger MSM than the set was created for, on a full device): plain accumulate
+    free_pair_ws(b);
+    b->no_pair = 1;
+    (void)hipGetLastError();
+    p = plan_for<C>(b, n);
+  }
   if (int rc = ensure_ws<C>(b, n, p)) return rc;
   g_last_plan[0] = p.c; g_last_plan[1] = p.W; g_last_plan[2] = p.pre; g_last_plan[3] = (int)p.T;
   for (int i = 0; i < 5; ++i)
@@ -454,12 +483,15 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   const unsigned gb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_rank, b->d_hist, n, p.c, p.W, p.pre ? 0u : p.nb);
   const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_hist, b->d_offsets, b->d_blocksums, (size_t)p.n_buckets);
+  // with pairing levels the offsets count groups of 2^levels entries and the padding of the sorted list is ENTRY_EMPTY
+  const uint32_t pshift = (uint32_t)p.pair_levels;
+  if (pshift) HIP_TRY(hipMemsetAsync(b->d_sorted, 0xff, sizeof(uint32_t) * ((size_t)p.W * n + (size_t)p.n_buckets * (((size_t)1 << pshift) - 1)), st));
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_hist, b->d_offsets, b->d_blocksums, (size_t)p.n_buckets, pshift);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
   hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total,
                      (size_t)p.n_buckets);
   hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_rank, b->d_offsets, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
-                     p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u);
+                     p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u, pshift);
   HIP_TRY(hipEventRecord(b->ev[1], st));
   // point stages: with the lane-split configuration of the group (Fq2: two lanes per point, Fq3: three) when it has
   // one, otherwise one lane per point.  MNT753_MSM_ACC=vm forces one lane.
@@ -467,8 +499,8 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   {
     int rc;
     using CS = typename SplitOf<C>::type;
-    if constexpr (!std::is_void<CS>::value) rc = use_split_acc<C>() ? point_stages<CS, C>(p, st, d_aff, b, &cur) : point_stages<C, C>(p, st, d_aff, b, &cur);
-    else rc = point_stages<C, C>(p, st, d_aff, b, &cur);
+    if constexpr (!std::is_void<CS>::value) rc = use_split_acc<C>() ? point_stages<CS, C>(p, n, st, d_aff, b, &cur) : point_stages<C, C>(p, n, st, d_aff, b, &cur);
+    else rc = point_stages<C, C>(p, n, st, d_aff, b, &cur);
     if (rc) return rc;
   }
   const uint32_t NS = p.n_sets;

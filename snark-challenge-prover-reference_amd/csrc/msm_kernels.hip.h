@@ -65,6 +65,36 @@ __device__ __forceinline__ void fp_store(uint32_t* p, const Fp<M>& a) {
     q[i] = v;
   }
 }
+// The 28th storage word of an element is padding; the pairing levels keep two flags of a ROW (affine point) in the pad
+// word of every component of its x coordinate: PF_EMPTY (the slot holds no point) and PF_NEG (the point is (x, -y)).
+constexpr uint32_t PF_EMPTY = 1u, PF_NEG = 2u;
+template <int M>
+__device__ __forceinline__ uint32_t fp_load_flag(Fp<M>& r, const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint32_t flag = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    uint4 v = q[i];
+    r.l[4 * i] = v.x;
+    r.l[4 * i + 1] = v.y;
+    r.l[4 * i + 2] = v.z;
+    if (4 * i + 3 < NL) r.l[4 * i + 3] = v.w; else flag = v.w;
+  }
+  return flag;
+}
+template <int M>
+__device__ __forceinline__ void fp_store_flag(uint32_t* p, const Fp<M>& a, uint32_t flag) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    uint4 v;
+    v.x = a.l[4 * i];
+    v.y = a.l[4 * i + 1];
+    v.z = a.l[4 * i + 2];
+    v.w = (4 * i + 3 < NL) ? a.l[4 * i + 3] : flag;
+    q[i] = v;
+  }
+}
 // ---- thread -> (logical lane, component) ------------------------------------------------------------------
 // One-lane fields: thread = logical lane.  Lane-split fields (FieldFp2S / FieldFp3S, curve753.hip.h): LANES adjacent
 // threads form one logical lane and each of them loads / stores only its own component of every element, so the
@@ -284,13 +314,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
   return base + x - v;
 }
 
+// scans ceil(in[i] / 2^shift): with shift = L the offsets count groups of 2^L entries -- the slot layout of L pairing levels
 static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                             uint32_t* __restrict__ block_sums, size_t n) {
+                                                             uint32_t* __restrict__ block_sums, size_t n, uint32_t shift) {
   size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS], s = 0;
+  const uint32_t rnd = (1u << shift) - 1u;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
-    v[k] = (base + k < n) ? in[base + k] : 0u;
+    v[k] = (base + k < n) ? ((in[base + k] + rnd) >> shift) : 0u;
     s += v[k];
   }
   uint32_t total;
@@ -342,16 +374,18 @@ static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_finish(uint32_t* _
 // ---- scatter: counting sort of (point, sign) by flattened bucket id ----------------------------
 // hist_stride = 2^(c-1) (one bucket set per window) or 0 (all windows share one bucket set: precomputed tables);
 // the sorted entry is the row index  w * entry_stride + entry_base + i  of the base table, plus the sign bit.
+// shift = L > 0: `offsets` counts groups of 2^L entries (k_scan_blocks) and every bucket's entries start at a multiple of 2^L in
+// `sorted` (the unused tail of a bucket's last group keeps the ENTRY_EMPTY the buffer was filled with).
 static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, const uint32_t* __restrict__ rank,
                                                 const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, size_t n, int c, int W,
-                                                uint32_t hist_stride, uint32_t entry_stride, uint32_t entry_base) {
+                                                uint32_t hist_stride, uint32_t entry_stride, uint32_t entry_base, uint32_t shift) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int w = 0; w < W; ++w) {
     const int32_t d = digits[(size_t)w * n + i];
     if (d == 0) continue;
     const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-    const uint32_t pos = offsets[(size_t)w * hist_stride + b] + rank[(size_t)w * n + i];   // no atomics: k_scalar_digits kept the rank
+    const uint32_t pos = (offsets[(size_t)w * hist_stride + b] << shift) + rank[(size_t)w * n + i];   // no atomics: k_scalar_digits kept the rank
     sorted[pos] = ((uint32_t)w * entry_stride + entry_base + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
   }
 }
@@ -434,162 +468,302 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
   }
 }
 
-// ---- pairing pass: batched affine additions ahead of the accumulate (G1) ------------------------------------
-// The sorted entry list is halved before the projective accumulate: inside every bucket, entries (2j, 2j+1) are added in
-// AFFINE coordinates -- 3 products (lambda, lambda^2, y3) plus 3 for Montgomery's simultaneous-inversion trick plus a
-// 1/B share of one divstep inversion (fp_inv.hip.h, ~94 product-equivalents) instead of the 11 of a mixed addition.
-// A lane owns B consecutive OUTPUT slots: forward sweep (running product of the denominators, prefix products to a
-// per-lane HBM workspace), one inversion, backward sweep (individual inverses, the sums).  Output: an affine point array
-// `pairpts` in the row format of the base table, a new entry list `sorted2` (slot -> row, no sign) and the bucket offsets
-// `offsets2` (scan of ceil(count / 2)), i.e. exactly the inputs of k_bucket_accumulate.
-// Side paths: an odd leftover is copied (with its sign applied); equal points are doubled (denominator 2y); opposite
-// points cancel: the slot gets the fixed point D (`gen`, the group generator) and fix_count[bucket] is incremented --
-// k_pair_fix subtracts fix_count * D from those buckets after the edge merge.  (The accumulate kernel is left exactly as
-// it is: every edit of its loop, even a skip test, cost 8-10 % through register allocation.)
-static __global__ void __launch_bounds__(256) k_pair_counts(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cnt2, uint32_t n_buckets) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < n_buckets) cnt2[b] = (offsets[b + 1] - offsets[b] + 1u) >> 1;
-}
+// ---- pairing levels: batched affine additions ahead of the accumulate ---------------------------------------
+// L levels halve the sorted entry list L times before the projective accumulate.  An affine addition costs 3 products
+// (lambda, lambda^2 -- a dedicated squaring on the base field --, y3) plus 3 for Montgomery's simultaneous-inversion trick
+// plus a 1/B share of one divstep inversion (fp_inv.hip.h, ~94 product-equivalents) instead of the 11 of a mixed addition.
+//
+// Slot layout: k_scan_blocks / k_scatter place every bucket's entries at a multiple of 2^L (offsG counts groups of 2^L; the
+// tail of a bucket's last group holds ENTRY_EMPTY), so the pairing is a REGULAR binary tree over slot indices: level-l slot o
+// adds level-(l-1) slots 2o and 2o+1 -- no bucket walk, no offset lookups, and slot o of level L is final slot o of the bucket
+// list the accumulate kernel reads with offsG.  Emptiness and the sign of y travel with the rows (PF_EMPTY / PF_NEG in the pad
+// word of x), so no y is ever negated: for P1 = (x1, s1 y1), P2 = (x2, s2 y2)
+//      s1 == s2:  lambda' = (y2 - y1) / (x2 - x1),  y3' = lambda' (x1 - x3) - y1,  result (x3,  s1 y3')
+//      s1 != s2:  lambda' = (y2 + y1) / (x2 - x1),  y3' = lambda' (x1 - x3) + y1,  result (x3,  s2 y3')
+// with x3 = lambda'^2 - x1 - x2 in both cases.
+//
+// Schedule: lane t handles slots t, t + NL, t + 2 NL, ... so adjacent lanes hold adjacent slots.  Forward sweep: x only,
+// running product of the denominators, prefix products and the slot's kind to HBM; one inversion per lane; backward sweep:
+// the sums.  One wave per SIMD: two were measured no faster (the stores below were the bottleneck, not latency) and halve
+// the batch length per inversion.
+//
+// Memory layout -- what the first version of this pass got wrong.  A 16-byte access per lane with a 112- or 224-byte lane
+// stride is 64 separate partial-sector requests per wave instruction; the 21 such stores per slot (prefix product + output
+// row) cost ~16k cycles of a ~85k-cycle slot, for every occupancy and every amount of prefetching, because the CU's one
+// address path serialises them.  Everything this pass writes for itself is therefore BLOCKED: element j (one Fp, 7 quads)
+// keeps quad q at uint4 index ((j / 64) * 7 + q) * 64 + j % 64, so that the 64 lanes of a wave (consecutive j) move one
+// contiguous KiB per instruction:
+//   * prefix products: j = slot * LANES + component;
+//   * rows handed to the NEXT pairing level: four planes (x | y) x (even | odd slot), j = (slot / 2) * LANES + component --
+//     the reader's slot o' takes x1, y1 from the even planes and x2, y2 from the odd planes at j = o' * LANES + component,
+//     the writer's lanes alternate between the two planes and still fill whole 64-byte sectors.
+// Only the two ends stay row-major (224-byte rows): level 1 gathers rows of the window table, the last level writes the
+// rows the accumulate kernel gathers.
+// Side paths: an odd leftover is copied with its sign flag; equal points are doubled (denominator 2y); opposite points
+// cancel: the slot gets the fixed point D (`gen`, the group generator) and fix_count[bucket] is incremented -- k_pair_fix
+// subtracts fix_count * D from those buckets after the edge merge, so the accumulate kernel never sees an empty slot.
+constexpr uint32_t ENTRY_EMPTY = 0xffffffffu;
+enum : uint32_t { PK_ADD = 0, PK_DBL = 1, PK_CANCEL = 2, PK_SINGLE = 3, PK_EMPTY = 4 };
+#ifdef MNT753_PAIR_TIMING
+// development: per-phase cycle totals of k_pair_level (s_memtime, one sample per wave)
+__device__ unsigned long long g_pair_cycles[8];
+#define PAIR_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PAIR_ACC(i, a, b) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_pair_cycles[i], (b) - (a)); } while (0)
+#define PAIR_SUM_DECL(v) unsigned long long v = 0
+#define PAIR_SUM(v, a, b) v += (b) - (a)
+#else
+#define PAIR_T(var)
+#define PAIR_ACC(i, a, b)
+#define PAIR_SUM_DECL(v)
+#define PAIR_SUM(v, a, b)
+#endif
 
-// Bucket walks of the pairing pass.  Buckets are usually adjacent, but a skewed scalar vector (all scalars equal: ~38
-// non-empty buckets out of 2^19) leaves thousands of empty ones between two slots, and a linear walk is one dependent load
-// per empty bucket in a lane the whole kernel then waits for: try the neighbour, else bisect.
-// first b' > b whose slot range ends after o (o < offs[n_buckets])
-__device__ __forceinline__ uint32_t bucket_after(const uint32_t* __restrict__ offs, uint32_t b, uint32_t o, uint32_t n_buckets) {
-  uint32_t lo = b + 1u;
-  if (offs[lo + 1u] > o) return lo;
-  uint32_t hi = n_buckets - 1u;
-  ++lo;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (offs[mid + 1u] > o) hi = mid; else lo = mid + 1u;
+// b + (negate ? -y : y) without a separate negation: the subtrahend / addend is chosen limb-wise
+template <int M>
+__device__ __forceinline__ void fp_addsub(Fp<M>& r, const Fp<M>& a, const Fp<M>& y, bool subtract) {
+  uint32_t s[NL];
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int32_t yi = subtract ? (int32_t)FPC[M].p2[i] - (int32_t)y.l[i] : (int32_t)y.l[i];
+    const int32_t t = (int32_t)a.l[i] + yi + c;
+    s[i] = (uint32_t)t & LMASK;
+    c = t >> LB;
   }
-  return lo;
+  fp_reduce2p<M>(r, s);
 }
-// last b' < b whose slot range starts at or before o
-__device__ __forceinline__ uint32_t bucket_before(const uint32_t* __restrict__ offs, uint32_t b, uint32_t o) {
-  if (offs[b - 1u] <= o) return b - 1u;
-  uint32_t lo = 0, hi = b - 2u;              // offs[0] = 0 <= o
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi + 1u) >> 1;
-    if (offs[mid] <= o) lo = mid; else hi = mid - 1u;
+
+// blocked element arrays (see above): uint4 index of quad 0 of element j; quad q is 64 uint4 further on
+__host__ __device__ __forceinline__ size_t blk_index(uint32_t j) { return (size_t)(j >> 6) * (7 * 64) + (j & 63u); }
+__host__ __device__ __forceinline__ size_t blk_quads(uint64_t n_elems) { return (size_t)((n_elems + 63) / 64) * (7 * 64); }   // uint4s of an array of n elements
+template <int M>
+__device__ __forceinline__ uint32_t fp_load_blk(Fp<M>& r, const uint4* __restrict__ base, uint32_t j) {
+  const uint4* q = base + blk_index(j);
+  uint32_t flag = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const uint4 v = q[(size_t)i * 64];
+    r.l[4 * i] = v.x;
+    r.l[4 * i + 1] = v.y;
+    r.l[4 * i + 2] = v.z;
+    if (4 * i + 3 < NL) r.l[4 * i + 3] = v.w; else flag = v.w;
   }
-  return lo;
+  return flag;
+}
+template <int M>
+__device__ __forceinline__ void fp_store_blk(uint4* __restrict__ base, uint32_t j, const Fp<M>& a, uint32_t flag) {
+  uint4* q = base + blk_index(j);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    uint4 v;
+    v.x = a.l[4 * i];
+    v.y = a.l[4 * i + 1];
+    v.z = a.l[4 * i + 2];
+    v.w = (4 * i + 3 < NL) ? a.l[4 * i + 3] : flag;
+    q[(size_t)i * 64] = v;
+  }
 }
 
-template <class C>
-__device__ __forceinline__ void pair_load(typename C::F::E& x, typename C::F::E& y, const uint32_t* __restrict__ table, uint32_t s) {
+// first: sources are rows of `src_rows` (the window table, row-major) named by the padded entry list; otherwise the four
+//        planes of the previous level at src_planes (plane stride src_stride uint4s).
+// last:  output rows row-major to out_rows plus the entry list out_sorted for the accumulate kernel; otherwise the four
+//        planes at out_planes (stride out_stride).
+template <class C, bool first, bool last>
+__global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restrict__ src_rows,
+                                                      const uint32_t* __restrict__ entries, const uint4* __restrict__ src_planes,
+                                                      size_t src_stride, const uint32_t* __restrict__ offsG, uint32_t n_buckets,
+                                                      uint32_t shift, uint32_t* __restrict__ out_rows, uint32_t* __restrict__ out_sorted,
+                                                      uint4* __restrict__ out_planes, size_t out_stride, uint4* __restrict__ prefix_ws,
+                                                      uint8_t* __restrict__ kind_ws, uint32_t min_B, uint32_t n_lanes,
+                                                      const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count, uint32_t dbg) {
   using F = typename C::F;
-  const uint32_t* src = table + (size_t)(s & 0x7fffffffu) * aff_words<C>();
-  e_load<F>(x, src);
-  e_load<F>(y, src + F::DEG * FPS_WORDS);
-  if (s & 0x80000000u) F::neg(y, y);
-}
-
-template <class C>
-__global__ void __launch_bounds__(256, 1) k_pair_add(const uint32_t* __restrict__ table, const uint32_t* __restrict__ sorted,
-                                                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ offsets2,
-                                                    uint32_t n_buckets, uint32_t* __restrict__ pairpts, uint32_t* __restrict__ sorted2,
-                                                    uint32_t* __restrict__ prefix_ws, uint32_t min_B, uint32_t n_lanes,
-                                                    const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count) {
-  using F = typename C::F;
-  using E = typename F::E;
-  constexpr int EW = F::DEG * FPS_WORDS;   // storage words of one element (lane-split fields store their own component)
+  using E = typename F::E;                 // a single Fp: base field, or one component per lane of a lane-split field
+  constexpr int M = F::MOD;
+  constexpr int EW = F::DEG * FPS_WORDS;   // storage words of one element (row-major rows)
+  constexpr int AW = aff_words<C>();
+  constexpr uint32_t LN = F::LANES;
   const uint32_t t = logical_lane<F>();
   if (t >= n_lanes) return;
-  const uint32_t total2 = offsets2[n_buckets];
-  // batch length from the ACTUAL number of slots (the host only knows the worst case W * n): witness vectors full of zero
-  // and one scalars leave a fraction of it, and a fixed B would leave most lanes idle behind a few long batches
-  const uint32_t B = max(min_B, (total2 + n_lanes - 1u) / n_lanes);
-  const uint64_t o0_64 = (uint64_t)t * B;
-  if (o0_64 >= total2) return;
-  const uint32_t o0 = (uint32_t)o0_64;
-  const uint32_t o1 = (o0_64 + B < total2) ? (uint32_t)(o0_64 + B) : total2;
-  uint32_t lo = 0, hi = n_buckets;   // largest b with offsets2[b] <= o0
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (offsets2[mid + 1] > o0) hi = mid; else lo = mid + 1;
-  }
-  uint32_t b = lo;
-  uint32_t nxt = offsets2[b + 1];
+  const uint32_t S = offsG[n_buckets] << shift;          // slots of this level (shift = levels still to come)
+  // batch length from the ACTUAL number of slots (the host only knows the worst case): witness vectors full of zero and one
+  // scalars leave a fraction of it, and a fixed B would leave most lanes idle behind a few long batches
+  const uint32_t B = max(min_B, (S + n_lanes - 1u) / n_lanes);
+  const uint32_t NLe = (S + B - 1u) / B;                  // lanes in use; slot = it * NLe + t
+  if (t >= NLe) return;
+  const uint32_t comp = lane_comp<F>();
+  const uint32_t cw = comp * FPS_WORDS;                   // this thread's component inside a row-major element
+  const uint2* ent2 = reinterpret_cast<const uint2*>(entries);
+  const uint32_t n_it = (S - t + NLe - 1u) / NLe;         // slots of this lane: t, t + NLe, ...
   E run, x1, y1, x2, y2, den, tmp;
   F::one(run);
-  // ---- forward: prefix products of the denominators
-  for (uint32_t o = o0; o < o1; ++o) {
-    if (o == nxt) { b = bucket_after(offsets2, b, o, n_buckets); nxt = offsets2[b + 1]; }
-    const uint32_t e0 = offsets[b] + 2u * (o - offsets2[b]);
-    e_store<F>(prefix_ws + ((size_t)(o - o0) * n_lanes + t) * EW, run);
-    if (e0 + 1u < offsets[b + 1]) {
-      const uint32_t s0 = sorted[e0], s1 = sorted[e0 + 1u];
-      // x only: the rows are gathered at random and this pass is bound by scattered HBM sectors, not by arithmetic
-      e_load<F>(x1, table + (size_t)(s0 & 0x7fffffffu) * aff_words<C>());
-      e_load<F>(x2, table + (size_t)(s1 & 0x7fffffffu) * aff_words<C>());
+  PAIR_T(tc0);
+  PAIR_SUM_DECL(sum_steps); PAIR_SUM_DECL(sum_loads);
+  // ---- forward: prefix products of the denominators, kinds
+  for (uint32_t o = t; o < S; o += NLe) {
+    uint32_t r0 = 0, r1 = 0, f0, f1;
+    if constexpr (first) {
+      const uint2 e = ent2[o];
+      f0 = e.x == ENTRY_EMPTY ? PF_EMPTY : (e.x >> 31) * PF_NEG;
+      f1 = e.y == ENTRY_EMPTY ? PF_EMPTY : (e.y >> 31) * PF_NEG;
+      r0 = (f0 & PF_EMPTY) ? 0u : (e.x & 0x7fffffffu);
+      r1 = (f1 & PF_EMPTY) ? 0u : (e.y & 0x7fffffffu);
+      if (dbg & 16u) { r0 = 2 * (o & 1023u); r1 = r0 + 1; }
+      fp_load(x1, src_rows + (size_t)r0 * AW + cw);
+      fp_load(x2, src_rows + (size_t)r1 * AW + cw);
+    } else {
+      f0 = fp_load_blk(x1, src_planes, o * LN + comp);
+      f1 = fp_load_blk(x2, src_planes + src_stride, o * LN + comp);
+    }
+    uint32_t kind;
+    if (f0 & PF_EMPTY) kind = PK_EMPTY;
+    else if (f1 & PF_EMPTY) kind = PK_SINGLE;
+    else {
+      kind = PK_ADD;
       F::sub(den, x2, x1);
       if (F::is_zero(den)) {
-        pair_load<C>(x1, y1, table, s0);
-        pair_load<C>(x2, y2, table, s1);
-        F::add(den, y1, y2);                 // equal points: 2y; opposite points: 0 -> take 1
-        if (F::is_zero(den)) F::one(den);
+        // same x: equal points (doubling, denominator 2y) or opposite points (cancellation, take 1)
+        if constexpr (first) {
+          fp_load(y1, src_rows + (size_t)r0 * AW + EW + cw);
+          fp_load(y2, src_rows + (size_t)r1 * AW + EW + cw);
+        } else {
+          (void)fp_load_blk(y1, src_planes + 2 * src_stride, o * LN + comp);
+          (void)fp_load_blk(y2, src_planes + 3 * src_stride, o * LN + comp);
+        }
+        fp_addsub<M>(den, y1, y2, ((f0 ^ f1) & PF_NEG) != 0);      // s1 y1 + s2 y2 up to the sign s1
+        if (F::is_zero(den)) { F::one(den); kind = PK_CANCEL; } else kind = PK_DBL;
       }
-      F::mul(tmp, run, den);
-      run = tmp;
+      if (!(dbg & 1u)) fp_store_blk(prefix_ws, o * LN + comp, run, 0u);
+      if (!(dbg & 8u)) { F::mul(tmp, run, den); run = tmp; } else F::add(run, run, den);
     }
+    kind_ws[(size_t)o * LN + comp] = (uint8_t)kind;   // one copy per thread: each reads back its own store
   }
   E inv;
+  PAIR_T(tc1);
   F::inv(inv, run);
-  // ---- backward: individual inverses and the sums
-  for (uint32_t o = o1; o-- > o0;) {
-    if (o < offsets2[b]) b = bucket_before(offsets2, b, o);
-    const uint32_t e0 = offsets[b] + 2u * (o - offsets2[b]);
-    uint32_t* dst = pairpts + (size_t)o * aff_words<C>();
-    pair_load<C>(x1, y1, table, sorted[e0]);
-    if (!(e0 + 1u < offsets[b + 1])) {       // odd leftover: copy
-      e_store<F>(dst, x1);
-      e_store<F>(dst + F::DEG * FPS_WORDS, y1);
-      sorted2[o] = o;
-      continue;
+  PAIR_T(tc2);
+  // ---- backward: individual inverses and the sums (highest slot of the lane first)
+  for (uint32_t it = n_it; it-- > 0;) {
+    const uint32_t o = it * NLe + t;
+    const uint32_t kind = kind_ws[(size_t)o * LN + comp];
+    uint32_t f0 = 0, f1 = 0;
+    E pre;
+    if constexpr (first) {
+      const uint2 e = ent2[o];
+      f0 = e.x == ENTRY_EMPTY ? PF_EMPTY : (e.x >> 31) * PF_NEG;
+      f1 = e.y == ENTRY_EMPTY ? PF_EMPTY : (e.y >> 31) * PF_NEG;
+      uint32_t r0 = (f0 & PF_EMPTY) ? 0u : (e.x & 0x7fffffffu);
+      uint32_t r1 = (f1 & PF_EMPTY) ? 0u : (e.y & 0x7fffffffu);
+      if (dbg & 16u) { r0 = 2 * (o & 1023u); r1 = r0 + 1; }
+      fp_load(x1, src_rows + (size_t)r0 * AW + cw);
+      fp_load(x2, src_rows + (size_t)r1 * AW + cw);
+      fp_load(y1, src_rows + (size_t)r0 * AW + EW + cw);
+      fp_load(y2, src_rows + (size_t)r1 * AW + EW + cw);
+    } else {
+      f0 = fp_load_blk(x1, src_planes, o * LN + comp);
+      f1 = fp_load_blk(x2, src_planes + src_stride, o * LN + comp);
+      (void)fp_load_blk(y1, src_planes + 2 * src_stride, o * LN + comp);
+      (void)fp_load_blk(y2, src_planes + 3 * src_stride, o * LN + comp);
     }
-    pair_load<C>(x2, y2, table, sorted[e0 + 1u]);
-    E lam, pre, invj;
-    F::sub(den, x2, x1);
-    int kind = 0;                            // 0 = addition, 1 = doubling, 2 = cancellation
-    if (F::is_zero(den)) {
-      F::add(den, y1, y2);
-      if (F::is_zero(den)) { F::one(den); kind = 2; } else kind = 1;
+    if (!(dbg & 4u)) (void)fp_load_blk(pre, prefix_ws, o * LN + comp); else pre = x1;
+    PAIR_T(tl0);
+    uint32_t out_flag = PF_EMPTY;
+    if (kind == PK_SINGLE) {                    // odd leftover: copy, the sign travels in the flag
+      out_flag = f0 & PF_NEG;
+      x2 = x1;
+    } else if (kind != PK_EMPTY) {
+      E num;
+      const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
+      out_flag = f1 & PF_NEG;
+      if (kind == PK_ADD) {
+        F::sub(den, x2, x1);
+        fp_addsub<M>(num, y2, y1, !flip);       // y2 - y1  or  y2 + y1
+      } else if (kind == PK_DBL) {
+        // P1 == P2 as signed points, s1 y1 = s2 y2: lambda = (3 x^2 + a) / (2 s1 y1) = s1 lambda' with the denominator 2 y1 formed
+        // exactly as in the forward sweep (y1 + y2, or y1 - y2 when the flags differ); result (x3, s1 (lambda' (x1 - x3) - y1))
+        E a;
+        fp_addsub<M>(den, y1, y2, flip);
+        F::mul(tmp, x1, x1);
+        F::add(num, tmp, tmp); F::add(num, num, tmp);
+        C::coeff_a(a);
+        F::add(num, num, a);
+        out_flag = f0 & PF_NEG;
+      } else {                                  // cancellation: the slot only takes part in the inversion chain (denominator 1)
+        F::one(den);
+        num = den;
+      }
+      PAIR_T(tl1);
+      PAIR_SUM(sum_loads, tl0, tl1);
+      // The five products of a slot run through ONE inlined multiplier (and one squarer) in a wave-uniform step loop; every
+      // result replaces an operand that is dead by then, which keeps the loop's live state at seven elements:
+      //   0: pre <- inv * pre  (= 1 / den)      1: inv <- inv * den        2: den <- num * pre  (= lambda)
+      //   3: x2 <- lambda^2 - x1 - x2 (= x3), num <- x1 - x3             4: y1 <- lambda * num -+ y1  (= y3')
+      {
+        E opa, opb, res;
+        PAIR_T(ta);
+#pragma nounroll
+        for (int step = (dbg & 32u) ? 4 : 0; step < 5; ++step) {
+          switch (step) {
+            case 0: opa = inv; opb = pre; break;
+            case 1: opa = inv; opb = den; break;
+            case 2: opa = num; opb = pre; break;
+            case 3: opa = den; opb = den; break;
+            default: opa = den; opb = num; break;
+          }
+          if constexpr (has_sqr<F>::value) {
+            if (step == 3) F::sqr(res, opa); else F::mul(res, opa, opb);
+          } else {
+            F::mul(res, opa, opb);
+          }
+          switch (step) {
+            case 0: pre = res; break;
+            case 1: inv = res; break;
+            case 2: den = res; break;
+            case 3:
+              F::sub(res, res, x1);
+              F::sub(x2, res, x2);
+              F::sub(num, x1, x2);
+              break;
+            default:
+              fp_addsub<M>(y1, res, y1, !(kind == PK_ADD && flip));
+              break;
+          }
+        }
+        PAIR_T(tb);
+        PAIR_SUM(sum_steps, ta, tb);
+      }
+      if (kind == PK_CANCEL) {                  // P + (-P): emit D, remember to take it out of the bucket again
+        fp_load(x2, gen + cw);
+        fp_load(y1, gen + EW + cw);
+        out_flag = 0;
+        if (comp == 0) {
+          const uint32_t f = o >> shift;        // final slot -> bucket: largest b with offsG[b] <= f
+          uint32_t lo = 0, hi = n_buckets - 1u;
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (offsG[mid] <= f) lo = mid; else hi = mid - 1u;
+          }
+          atomicAdd(&fix_count[lo], 1u);
+        }
+      }
     }
-    e_load<F>(pre, prefix_ws + ((size_t)(o - o0) * n_lanes + t) * EW);
-    F::mul(invj, inv, pre);                  // 1 / den
-    F::mul(tmp, inv, den);                   // inverse of the product of the remaining denominators
-    inv = tmp;
-    if (kind == 2) {                         // P + (-P): emit D, remember to take it out of bucket b again
-      e_load<F>(x2, gen);
-      e_load<F>(y2, gen + F::DEG * FPS_WORDS);
-      e_store<F>(dst, x2);
-      e_store<F>(dst + F::DEG * FPS_WORDS, y2);
-      sorted2[o] = o;
-      if (lane_comp<F>() == 0) atomicAdd(&fix_count[b], 1u);
-      continue;
+    // result (x2, y1) with out_flag (an empty slot only needs its flag; the coordinates written with it are never used)
+    if (dbg & 2u) {
+      if (x2.l[0] == 0x12345u && y1.l[3] == 0x777u) kind_ws[0] = 1;   // keep the values alive
+    } else if constexpr (last) {
+      uint32_t* dst = out_rows + (size_t)o * AW;
+      fp_store_flag(dst + cw, x2, out_flag);
+      fp_store(dst + EW + cw, y1);
+      if (comp == 0) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : (o | ((out_flag & PF_NEG) ? 0x80000000u : 0u));
+    } else {
+      const uint32_t j = (o >> 1) * LN + comp;
+      uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
+      fp_store_blk(px, j, x2, out_flag);
+      fp_store_blk(px + 2 * out_stride, j, y1, 0u);
     }
-    if (kind == 0) {
-      F::sub(lam, y2, y1);
-    } else {                                 // 3 x^2 + a
-      F::mul(tmp, x1, x1);
-      F::add(lam, tmp, tmp); F::add(lam, lam, tmp);
-      C::coeff_a(tmp);
-      F::add(lam, lam, tmp);
-    }
-    F::mul(tmp, lam, invj);
-    lam = tmp;
-    F::mul(tmp, lam, lam);                   // x3 = lambda^2 - x1 - x2
-    F::sub(tmp, tmp, x1);
-    F::sub(x2, tmp, x2);
-    F::sub(tmp, x1, x2);                     // y3 = lambda (x1 - x3) - y1
-    F::mul(den, lam, tmp);
-    F::sub(y2, den, y1);
-    e_store<F>(dst, x2);
-    e_store<F>(dst + F::DEG * FPS_WORDS, y2);
-    sorted2[o] = o;
   }
+  PAIR_T(tc3);
+  PAIR_ACC(0, tc0, tc1); PAIR_ACC(1, tc1, tc2); PAIR_ACC(2, tc2, tc3); PAIR_ACC(3, 0ull, 1ull);
+  PAIR_ACC(5, 0ull, sum_steps); PAIR_ACC(6, 0ull, sum_loads);
 }
 
 template <class C>

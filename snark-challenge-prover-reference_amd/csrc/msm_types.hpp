@@ -15,6 +15,7 @@ struct MsmPlan {
   uint32_t n_chunks;  // n_sets * nb / L
   int pre;            // 1: all windows share one bucket set (precomputed window multiples)
   uint32_t n_sets;    // bucket sets: W, or 1 with the table
+  int pair_levels;    // batched-affine pairing levels ahead of the accumulate (0 = none): buckets are padded to 2^pair_levels entries
 };
 }  // namespace mnt753
 
@@ -33,11 +34,13 @@ struct mnt753_bases {
   uint32_t* d_sorted = nullptr;
   uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr, *d_edge_tmp = nullptr, *d_edge_flags = nullptr;
   uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;
-  // pairing pass (batched affine additions ahead of the accumulate, MNT753_MSM_PAIR=1): allocated on first use
-  uint32_t *d_cnt2 = nullptr, *d_pair_ws = nullptr, *d_fix = nullptr, *d_gen = nullptr;
-  uint32_t *d_offsets2[2] = {nullptr, nullptr}, *d_pairpts[2] = {nullptr, nullptr}, *d_sorted2[2] = {nullptr, nullptr};   // ping-pong over the levels
-  size_t pair_cap = 0;   // output slots of the first level the pairing buffers hold
-  size_t pair_buckets = 0;   // buckets the per-bucket pairing buffers hold
+  // pairing levels (batched affine additions ahead of the accumulate): grow-only buffers
+  uint32_t *d_pair_ws = nullptr, *d_fix = nullptr, *d_gen = nullptr;   // prefix products, cancellation counts per bucket, the stand-in point D
+  uint8_t* d_pair_kind = nullptr;                                       // kind of every slot of the level in flight
+  uint32_t *d_pairpts[2] = {nullptr, nullptr}, *d_sorted2 = nullptr;    // rows of the levels (ping-pong), entry list of the last level
+  size_t pair_cap = 0;   // level-1 slots the pairing buffers hold
+  size_t pair_buckets = 0;   // buckets d_fix holds
+  size_t sorted_cap = 0;     // entries d_sorted holds (padded layout: W*n + n_buckets*(2^levels - 1))
   int no_pair = 0;       // the pairing workspace could not be allocated: this set runs the plain accumulate
   uint32_t* d_wire_out = nullptr;
   uint64_t* h_wire_out = nullptr;   // pinned

@@ -1,4 +1,4 @@
-// ./main_hip <curve> compute <params> <input> <output> [--fused-h] [--h-first|--h-last] [--quiet]
+// ./main_hip <curve> compute <params> <input> <output> [--unfused-h] [--ref-order] [--quiet]
 //
 // The prover driver, same command line as the reference binaries (libsnark/main.cpp:274-293,
 // cuda_prover_piecewise.cu:100-120).  compute_H<B> and run_prover<B> keep the reference's shape -- they are
@@ -13,9 +13,15 @@
 
 #include "../../include/prover_hip_functions.hpp"
 
-static bool g_fused_h = false;
+// Defaults = the fastest schedule on one MI355X: the G2 MSM is enqueued as soon as w is on the device, compute_H (one fused
+// call) follows as soon as ca / cb / cc are, then the four G1 MSMs.  The point kernels occupy every SIMD with long-lived
+// workgroups, so the ~60 short NTT kernels of compute_H must not be enqueued behind four MSMs (measured: 0.24 s with this
+// order, 0.44-1.1 s with the reference's source order).  --ref-order keeps the order of cuda_prover_piecewise.cu:64-81,
+// --unfused-h the reference's sequence of B:: calls inside compute_H (cuda_prover_piecewise.cu:24-47); every combination
+// writes the same bytes.
+static bool g_fused_h = true;
 static bool g_quiet = false;
-static bool g_h_first = false;   // --h-first: compute_H and the H MSM before the other three G1 MSMs
+static bool g_h_first = true;
 
 typedef std::chrono::steady_clock clk;
 static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
@@ -124,14 +130,15 @@ void run_prover(const char* params_path, const char* input_path, const char* out
 int main(int argc, char** argv) {
   setbuf(stdout, NULL);
   if (argc < 6) {
-    fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [--fused-h] [--h-first|--h-last] [--quiet]\n", argv[0]);
+    fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [--unfused-h] [--ref-order] [--quiet]\n", argv[0]);
     return 2;
   }
   for (int i = 6; i < argc; ++i) {
     if (!strcmp(argv[i], "--fused-h")) g_fused_h = true;
+    else if (!strcmp(argv[i], "--unfused-h")) g_fused_h = false;
     else if (!strcmp(argv[i], "--quiet")) g_quiet = true;
     else if (!strcmp(argv[i], "--h-first")) g_h_first = true;
-    else if (!strcmp(argv[i], "--h-last")) g_h_first = false;
+    else if (!strcmp(argv[i], "--h-last") || !strcmp(argv[i], "--ref-order")) g_h_first = false;
   }
   std::string curve(argv[1]), mode(argv[2]);
   try {

@@ -45,7 +45,7 @@ def test_full_prove_matches_reference_hash(gpu, key, tmp_path):
     assert os.path.getsize(params) == e["params_bytes"] and os.path.getsize(inp) == e["input_bytes"]
     assert sha256_file(params) == e["params_sha256"], "synthetic parameter file differs from the one the reference proved"
     assert sha256_file(inp) == e["input_sha256"], "synthetic input file differs from the one the reference proved"
-    for flags in ([], ["--fused-h"]):
+    for flags in ([], ["--unfused-h", "--ref-order"]):
         r = subprocess.run([EXE, e["curve"], "compute", params, inp, out] + flags, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         assert os.path.getsize(out) == e["output_bytes"]

@@ -18,7 +18,7 @@ NAME = {0: "MNT4753", 1: "MNT6753"}
 
 
 @pytest.mark.parametrize("curve", [0, 1])
-@pytest.mark.parametrize("flags", [[], ["--fused-h"], ["--h-first"], ["--fused-h", "--h-first"]])
+@pytest.mark.parametrize("flags", [[], ["--unfused-h"], ["--ref-order"], ["--unfused-h", "--ref-order"]])
 def test_reference_proof_files(gpu, curve, flags, tmp_path):
     params, inp, expected = G.e2e_paths(curve)
     out = str(tmp_path / "proof.bin")
