@@ -107,10 +107,9 @@ int point_lanes() {
   else return use_split_acc<C>() ? CS::F::LANES : 1;
 }
 void free_pair_ws(mnt753_bases* b) {
-  void* ptrs[] = {b->d_pair_ws, b->d_fix, b->d_gen, b->d_pair_kind, b->d_pairpts[0], b->d_pairpts[1], b->d_sorted2};
+  void* ptrs[] = {b->d_pair_ws, b->d_fix, b->d_gen, b->d_pairpts[0], b->d_pairpts[1], b->d_sorted2};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   b->d_pair_ws = b->d_fix = b->d_gen = b->d_sorted2 = nullptr;
-  b->d_pair_kind = nullptr;
   b->d_pairpts[0] = b->d_pairpts[1] = nullptr;
   b->pair_cap = 0;
   b->pair_buckets = 0;
@@ -243,10 +242,10 @@ void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
 }
 
 // Pairing levels (k_pair_level, MNT753_MSM_PAIR = number of levels) + accumulate over the shortened list.
-// Lanes per level: two rounds of the machine at two waves per SIMD; minimum additions per inversion: keeps its share below one
+// Lanes per level: one round of the machine at one wave per SIMD; minimum additions per inversion: keeps its share below one
 // product per addition.  MNT753_PAIR_LANES / MNT753_PAIR_MINB are development overrides.
 inline uint32_t pair_env(const char* name, uint32_t dflt) { const char* e = getenv(name); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; }
-#define PAIR_MAX_LANES pair_env("MNT753_PAIR_LANES", 131072u)
+#define PAIR_MAX_LANES pair_env("MNT753_PAIR_LANES", 65536u)
 #define PAIR_MIN_B pair_env("MNT753_PAIR_MINB", 48u)
 // levels of the pairing pass for an MSM with `entries` sorted entries: below the measured crossover the per-level
 // inversion latency and the short batches cost more than the saved products;
@@ -287,7 +286,6 @@ int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p, size_t n) {
     HIP_TRY(hipMalloc(&b->d_pairpts[1], sizeof(uint32_t) * aff_words<V>() * (capA / 2 + 1) + slack * V::F::DEG));   // levels 2, 4, 6
     HIP_TRY(hipMalloc(&b->d_sorted2, sizeof(uint32_t) * capA));                                 // entry list of the last level
     HIP_TRY(hipMalloc(&b->d_pair_ws, 16 * blk_quads((uint64_t)capA * V::F::LANES + 64)));       // one prefix product per slot (blocked)
-    HIP_TRY(hipMalloc(&b->d_pair_kind, (size_t)capA * V::F::LANES));
     // D: the group generator in device form (wire constant -> k_bases_to_internal)
     uint32_t* wire = nullptr; uint8_t* inf = nullptr;
     const size_t gen_bytes = 192 * (size_t)C::F::DEG;
@@ -331,7 +329,8 @@ template <class V, class C>
 int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, uint32_t* acc_lanes) {
   if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
     const int levels = p.pair_levels;
-    const uint32_t max_lanes = PAIR_MAX_LANES / (uint32_t)V::F::LANES;   // logical lanes
+    // logical lanes: one workgroup per CU (the level kernels take 145 KB of LDS), 21 triples per wave for three-lane fields
+    const uint32_t max_lanes = V::F::LANES == 3 ? std::min<uint32_t>(PAIR_MAX_LANES / 3u, 21504u) : PAIR_MAX_LANES / (uint32_t)V::F::LANES;
     const uint32_t min_B = PAIR_MIN_B;
     if (int rc = ensure_pair_ws<V, C>(b, p, n)) return rc;
     HIP_TRY(hipMemsetAsync(b->d_fix, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
@@ -347,26 +346,30 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
       // planes of a level that feeds another one: (x | y) x (even | odd slot), each holding cap / 2 slots, blocked
       const size_t out_stride = blk_quads((cap / 2 + 1) * (uint64_t)V::F::LANES + 64);
 #define MNT753_PAIR_LAUNCH(FST, LST)                                                                                                         \
-  hipLaunchKernelGGL((k_pair_level<V, FST, LST>), dim3(blocks_for<typename V::F>(lanes)), dim3(256), 0, st, d_aff, b->d_sorted, src_planes, src_stride, \
-                     b->d_offsets, p.n_buckets, (uint32_t)(levels - l), out, b->d_sorted2, reinterpret_cast<uint4*>(out), out_stride,              \
-                     reinterpret_cast<uint4*>(b->d_pair_ws), b->d_pair_kind, min_B, lanes, b->d_gen, b->d_fix, pair_env("MNT753_PAIR_DBG", 0u))
+  do {                                                                                                                                      \
+    static bool lds_set = false;   /* the level kernels stage their operands in 145 KB of dynamic LDS per workgroup */                      \
+    if (!lds_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_level<V, FST, LST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS_BYTES)); lds_set = true; } \
+    hipLaunchKernelGGL((k_pair_level<V, FST, LST>), dim3(blocks_for<typename V::F>(lanes)), dim3(256), PAIR_LDS_BYTES, st, d_aff, b->d_sorted, src_planes, \
+                       src_stride, b->d_offsets, p.n_buckets, (uint32_t)(levels - l), out, b->d_sorted2, reinterpret_cast<uint4*>(out), out_stride,  \
+                       reinterpret_cast<uint4*>(b->d_pair_ws), min_B, lanes, b->d_gen, b->d_fix);                              \
+  } while (0)
       if (first && last) MNT753_PAIR_LAUNCH(true, true);
       else if (first) MNT753_PAIR_LAUNCH(true, false);
       else if (last) MNT753_PAIR_LAUNCH(false, true);
       else MNT753_PAIR_LAUNCH(false, false);
 #undef MNT753_PAIR_LAUNCH
-      src_planes = reinterpret_cast<const uint4*>(out);
-      src_stride = out_stride;
-      last_rows = out;
 #ifdef MNT753_PAIR_TIMING
       {
         unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pair_cycles), sizeof(h));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_cycles), z, sizeof(z));
-        if (h[3]) fprintf(stderr, "pair level %d: waves %llu  cycles/wave: forward %.0f  inversion %.0f  backward %.0f (wait+sub %.0f, steps %.0f)\n", l, h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[6] / h[3], (double)h[5] / h[3]);
+        if (h[3]) fprintf(stderr, "pair level %d: waves %llu  cycles/wave: forward %.0f  inversion %.0f  backward %.0f  [4] %.0f [5] %.0f [6] %.0f\n", l, h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[3], (double)h[5] / h[3], (double)h[6] / h[3]);
       }
 #endif
+      src_planes = reinterpret_cast<const uint4*>(out);
+      src_stride = out_stride;
+      last_rows = out;
     }
     const uint32_t* src = last_rows;
     // accumulate over at most `cap` entries: one round of the machine

@@ -504,19 +504,6 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
 // subtracts fix_count * D from those buckets after the edge merge, so the accumulate kernel never sees an empty slot.
 constexpr uint32_t ENTRY_EMPTY = 0xffffffffu;
 enum : uint32_t { PK_ADD = 0, PK_DBL = 1, PK_CANCEL = 2, PK_SINGLE = 3, PK_EMPTY = 4 };
-#ifdef MNT753_PAIR_TIMING
-// development: per-phase cycle totals of k_pair_level (s_memtime, one sample per wave)
-__device__ unsigned long long g_pair_cycles[8];
-#define PAIR_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define PAIR_ACC(i, a, b) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_pair_cycles[i], (b) - (a)); } while (0)
-#define PAIR_SUM_DECL(v) unsigned long long v = 0
-#define PAIR_SUM(v, a, b) v += (b) - (a)
-#else
-#define PAIR_T(var)
-#define PAIR_ACC(i, a, b)
-#define PAIR_SUM_DECL(v)
-#define PAIR_SUM(v, a, b)
-#endif
 
 // b + (negate ? -y : y) without a separate negation: the subtrahend / addend is chosen limb-wise
 template <int M>
@@ -564,6 +551,54 @@ __device__ __forceinline__ void fp_store_blk(uint4* __restrict__ base, uint32_t 
   }
 }
 
+// ---- LDS staging of everything the sweeps read ----------------------------------------------------------------
+// Gathering table rows one lane per row (7 x global_load_dwordx4 with a different row in every lane) reads 6 G rows/s on
+// MI355X -- 64 address translations and 64 partial-sector requests per instruction -- and made level 1 gather-bound (the
+// forward sweep took the same 25 k cycles per slot with or without its product).  Fetched ROW-COOPERATIVELY by LDS-DMA
+// (global_load_lds_dwordx4: consecutive lanes fetch consecutive 16-byte pieces of a row, 4-9 rows per instruction, straight
+// into LDS with no VGPR in between) the same rows arrive at 27 G rows/s (tools/experiments/gather_bench.hip).  The sweeps
+// therefore read ALL their inputs through a per-wave LDS image that is filled one slot ahead of the arithmetic:
+//     top of a slot:  s_waitcnt vmcnt(0)  ->  ds_read the slot's operands  ->  issue the LDS-DMA of the NEXT slot  ->  products
+// One wave per SIMD, 36 KB of LDS per wave.  Image of a wave (uint4 units):
+//     rows   first level: [point 0 | 1][slot of the wave][quads of the row (x | y) or of x only]   (packed, lane-linear fill)
+//            later levels: [plane x-even | x-odd | y-even | y-odd][quad][thread]                    (own data, already coalesced)
+//     pre    [quad][thread] (the slot's kind rides in its pad word)     entries [2 buffers][2 * slots of the wave]  (first level: fetched two slots ahead)
+constexpr uint32_t PAIR_IMG_QUADS = 1792;                       // 2 points x 64 lanes x 14 quads (every field: NS * RQ * 2 <= 1792)
+constexpr uint32_t PAIR_LDS_WAVE_QUADS = PAIR_IMG_QUADS + 448 + 64;   // rows, prefix product, entries (2 x 128 u32)
+constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
+
+#ifdef MNT753_PAIR_TIMING
+// development: cycle totals of k_pair_level per wave (s_memtime): [0] forward, [1] inversion, [2] backward, [3] waves, [4..] ad hoc
+__device__ unsigned long long g_pair_cycles[8];
+#define PAIR_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PAIR_ACC(i, a, b) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_pair_cycles[i], (unsigned long long)((b) - (a))); } while (0)
+#else
+#define PAIR_T(var)
+#define PAIR_ACC(i, a, b)
+#endif
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void glds16(const void* gsrc, const uint4* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr_t)lds_dst_wave_uniform, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* gsrc, const uint32_t* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr_t)lds_dst_wave_uniform, 4, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); }     // vmcnt(0)
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); asm volatile("" ::: "memory"); }   // lgkmcnt(0)
+template <int M>
+__device__ __forceinline__ uint32_t fp_from_lds(Fp<M>& r, const uint4* p, uint32_t stride) {   // 7 quads at p, p + stride, ...
+  uint32_t flag = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const uint4 v = p[(size_t)i * stride];
+    r.l[4 * i] = v.x;
+    r.l[4 * i + 1] = v.y;
+    r.l[4 * i + 2] = v.z;
+    if (4 * i + 3 < NL) r.l[4 * i + 3] = v.w; else flag = v.w;
+  }
+  return flag;
+}
+
 // first: sources are rows of `src_rows` (the window table, row-major) named by the padded entry list; otherwise the four
 //        planes of the previous level at src_planes (plane stride src_stride uint4s).
 // last:  output rows row-major to out_rows plus the entry list out_sorted for the accumulate kernel; otherwise the four
@@ -574,57 +609,131 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
                                                       size_t src_stride, const uint32_t* __restrict__ offsG, uint32_t n_buckets,
                                                       uint32_t shift, uint32_t* __restrict__ out_rows, uint32_t* __restrict__ out_sorted,
                                                       uint4* __restrict__ out_planes, size_t out_stride, uint4* __restrict__ prefix_ws,
-                                                      uint8_t* __restrict__ kind_ws, uint32_t min_B, uint32_t n_lanes,
-                                                      const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count, uint32_t dbg) {
+                                                      uint32_t min_B, uint32_t n_lanes,
+                                                      const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count) {
   using F = typename C::F;
   using E = typename F::E;                 // a single Fp: base field, or one component per lane of a lane-split field
   constexpr int M = F::MOD;
   constexpr int EW = F::DEG * FPS_WORDS;   // storage words of one element (row-major rows)
   constexpr int AW = aff_words<C>();
   constexpr uint32_t LN = F::LANES;
-  const uint32_t t = logical_lane<F>();
-  if (t >= n_lanes) return;
+  constexpr uint32_t NS = 64u / LN;                       // slots of a wave (21 for three lanes per point)
+  constexpr uint32_t RQ = 14u * F::DEG;                   // quads of a table row (x | y)
+  constexpr uint32_t XQ = 7u * F::DEG;                    // quads of its x coordinate
+  static_assert(2 * NS * RQ <= PAIR_IMG_QUADS, "row image");
+  extern __shared__ uint4 pair_lds[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint4* img = pair_lds + (size_t)wave * PAIR_LDS_WAVE_QUADS;
+  uint4* pre_img = img + PAIR_IMG_QUADS;
+  uint32_t* ent_img = reinterpret_cast<uint32_t*>(pre_img + 448);   // [2][128]
+
   const uint32_t S = offsG[n_buckets] << shift;          // slots of this level (shift = levels still to come)
   // batch length from the ACTUAL number of slots (the host only knows the worst case): witness vectors full of zero and one
   // scalars leave a fraction of it, and a fixed B would leave most lanes idle behind a few long batches
   const uint32_t B = max(min_B, (S + n_lanes - 1u) / n_lanes);
   const uint32_t NLe = (S + B - 1u) / B;                  // lanes in use; slot = it * NLe + t
-  if (t >= NLe) return;
+  // wave-uniform bookkeeping: every lane of a wave takes part in the cooperative loads, also lanes without a slot of their own
+  const uint32_t t0w = (blockIdx.x * (blockDim.x >> 6) + wave) * NS;   // first logical lane of the wave
+  if (t0w >= NLe || S == 0) return;
+  const uint32_t t = logical_lane<F>();                   // 0xffffffff for the idle 64th lane of three-lane fields
   const uint32_t comp = lane_comp<F>();
-  const uint32_t cw = comp * FPS_WORDS;                   // this thread's component inside a row-major element
-  const uint2* ent2 = reinterpret_cast<const uint2*>(entries);
-  const uint32_t n_it = (S - t + NLe - 1u) / NLe;         // slots of this lane: t, t + NLe, ...
+  const uint32_t sl = LN == 3 ? min(lane / 3u, NS - 1u) : lane / LN;   // this thread's slot inside the wave
+  const bool lane_on = t < NLe;
+  const uint32_t n_it = (S - t0w + NLe - 1u) / NLe;       // iterations of the wave (its first lane has the most slots)
+  const uint32_t cw = comp * FPS_WORDS;
+  const uint4* table = reinterpret_cast<const uint4*>(src_rows);
   E run, x1, y1, x2, y2, den, tmp;
   F::one(run);
-  PAIR_T(tc0);
-  PAIR_SUM_DECL(sum_steps); PAIR_SUM_DECL(sum_loads);
-  // ---- forward: prefix products of the denominators, kinds
-  for (uint32_t o = t; o < S; o += NLe) {
-    uint32_t r0 = 0, r1 = 0, f0, f1;
+
+  // LDS-DMA of the entry pairs of the wave's slots at iteration `it` -> ent_img[buf]
+  auto issue_entries = [=](uint32_t it, uint32_t buf) __attribute__((always_inline)) {
+    const uint32_t ob = it * NLe + t0w;                   // first slot of the wave
+    // 2 * NS u32, clamped to the padded list (slots >= S belong to no lane)
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {
+      const uint32_t i = 64u * k + lane;
+      const uint32_t slot = min(ob + (i >> 1), S - 1u);
+      glds4(entries + 2 * (size_t)slot + (i & 1u), ent_img + buf * 128u + 64u * k);
+    }
+  };
+  // LDS-DMA instruction k of the rows of iteration `it` (entries already in ent_img[buf]); xonly = x coordinates only (forward
+  // sweep).  first: 2 * NS * rq quads in image order, 64 per instruction; later levels: one instruction per (plane, quad).
+  auto issue_row_piece = [=](uint32_t it, uint32_t buf, uint32_t k, auto xonly_c) __attribute__((always_inline)) {
+    constexpr bool xonly = decltype(xonly_c)::value;
     if constexpr (first) {
-      const uint2 e = ent2[o];
-      f0 = e.x == ENTRY_EMPTY ? PF_EMPTY : (e.x >> 31) * PF_NEG;
-      f1 = e.y == ENTRY_EMPTY ? PF_EMPTY : (e.y >> 31) * PF_NEG;
-      r0 = (f0 & PF_EMPTY) ? 0u : (e.x & 0x7fffffffu);
-      r1 = (f1 & PF_EMPTY) ? 0u : (e.y & 0x7fffffffu);
-      if (dbg & 16u) { r0 = 2 * (o & 1023u); r1 = r0 + 1; }
-      fp_load(x1, src_rows + (size_t)r0 * AW + cw);
-      fp_load(x2, src_rows + (size_t)r1 * AW + cw);
+      constexpr uint32_t rq = xonly ? XQ : RQ;
+      constexpr uint32_t total = 2u * NS * rq;
+      const uint32_t i = min(64u * k + lane, total - 1u);
+      const uint32_t rs = i / rq, q = i - rs * rq;       // row slot = point * NS + slot
+      const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
+      const uint32_t e = ent_img[buf * 128u + 2u * s + p];
+      const uint32_t r = e == ENTRY_EMPTY ? 0u : (e & 0x7fffffffu);
+      glds16(table + (size_t)r * RQ + q, img + 64u * k);
     } else {
-      f0 = fp_load_blk(x1, src_planes, o * LN + comp);
-      f1 = fp_load_blk(x2, src_planes + src_stride, o * LN + comp);
+      const uint32_t o = min(it * NLe + (lane_on ? t : t0w), S - 1u);
+      const uint32_t j = o * LN + comp;
+      const uint32_t pl = k / 7u, q = k - pl * 7u;
+      glds16(src_planes + blk_index(j) + (size_t)pl * src_stride + (size_t)q * 64, img + k * 64u);
+    }
+  };
+  constexpr uint32_t ROW_PIECES_X = first ? (2u * NS * XQ + 63u) / 64u : 14u;
+  constexpr uint32_t ROW_PIECES = first ? (2u * NS * RQ + 63u) / 64u : 28u;
+  auto issue_rows = [=](uint32_t it, uint32_t buf, auto xonly_c) __attribute__((always_inline)) {
+    constexpr uint32_t n = decltype(xonly_c)::value ? ROW_PIECES_X : ROW_PIECES;
+#pragma unroll
+    for (uint32_t k = 0; k < n; ++k) issue_row_piece(it, buf, k, xonly_c);
+  };
+  // this thread's operands of the current slot, out of the image
+  auto read_rows = [=](uint32_t buf, auto xonly_c, uint32_t& f0, uint32_t& f1, E& x1, E& y1, E& x2, E& y2) __attribute__((always_inline)) {
+    constexpr bool xonly = decltype(xonly_c)::value;
+    if constexpr (first) {
+      constexpr uint32_t rq = xonly ? XQ : RQ;
+      const uint32_t e0 = ent_img[buf * 128u + 2u * sl], e1 = ent_img[buf * 128u + 2u * sl + 1u];
+      f0 = e0 == ENTRY_EMPTY ? PF_EMPTY : (e0 >> 31) * PF_NEG;
+      f1 = e1 == ENTRY_EMPTY ? PF_EMPTY : (e1 >> 31) * PF_NEG;
+      const uint4* p0 = img + (size_t)sl * rq + comp * 7u;
+      const uint4* p1 = img + (size_t)(NS + sl) * rq + comp * 7u;
+      (void)fp_from_lds(x1, p0, 1u);
+      (void)fp_from_lds(x2, p1, 1u);
+      if constexpr (!xonly) { (void)fp_from_lds(y1, p0 + XQ, 1u); (void)fp_from_lds(y2, p1 + XQ, 1u); }
+    } else {
+      f0 = fp_from_lds(x1, img + lane, 64u);
+      f1 = fp_from_lds(x2, img + 7u * 64u + lane, 64u);
+      if constexpr (!xonly) { (void)fp_from_lds(y1, img + 14u * 64u + lane, 64u); (void)fp_from_lds(y2, img + 21u * 64u + lane, 64u); }
+    }
+  };
+
+  // ---- forward: prefix products of the denominators, kinds
+  PAIR_T(tc0);
+  if constexpr (first) {
+    issue_entries(0, 0);
+    wait_vm0();
+    issue_entries(min(1u, n_it - 1u), 1);
+  }
+  issue_rows(0, 0, std::true_type{});
+  for (uint32_t it = 0; it < n_it; ++it) {
+    const uint32_t o = it * NLe + t;
+    const bool on = lane_on && o < S;
+    uint32_t f0, f1;
+    wait_vm0();
+    read_rows(it & 1u, std::true_type{}, f0, f1, x1, y1, x2, y2);
+    wait_lgkm0();
+    if (it + 1u < n_it) {
+      if constexpr (first) issue_entries(min(it + 2u, n_it - 1u), it & 1u);
+      issue_rows(it + 1u, (it + 1u) & 1u, std::true_type{});
     }
     uint32_t kind;
-    if (f0 & PF_EMPTY) kind = PK_EMPTY;
+    if (!on || (f0 & PF_EMPTY)) kind = PK_EMPTY;
     else if (f1 & PF_EMPTY) kind = PK_SINGLE;
     else {
       kind = PK_ADD;
       F::sub(den, x2, x1);
       if (F::is_zero(den)) {
-        // same x: equal points (doubling, denominator 2y) or opposite points (cancellation, take 1)
+        // same x: equal points (doubling, denominator 2y) or opposite points (cancellation, take 1).  Rare: plain loads.
         if constexpr (first) {
-          fp_load(y1, src_rows + (size_t)r0 * AW + EW + cw);
-          fp_load(y2, src_rows + (size_t)r1 * AW + EW + cw);
+          const uint2 e = reinterpret_cast<const uint2*>(entries)[o];
+          fp_load(y1, src_rows + (size_t)(e.x & 0x7fffffffu) * AW + EW + cw);
+          fp_load(y2, src_rows + (size_t)(e.y & 0x7fffffffu) * AW + EW + cw);
         } else {
           (void)fp_load_blk(y1, src_planes + 2 * src_stride, o * LN + comp);
           (void)fp_load_blk(y2, src_planes + 3 * src_stride, o * LN + comp);
@@ -632,105 +741,124 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
         fp_addsub<M>(den, y1, y2, ((f0 ^ f1) & PF_NEG) != 0);      // s1 y1 + s2 y2 up to the sign s1
         if (F::is_zero(den)) { F::one(den); kind = PK_CANCEL; } else kind = PK_DBL;
       }
-      if (!(dbg & 1u)) fp_store_blk(prefix_ws, o * LN + comp, run, 0u);
-      if (!(dbg & 8u)) { F::mul(tmp, run, den); run = tmp; } else F::add(run, run, den);
     }
-    kind_ws[(size_t)o * LN + comp] = (uint8_t)kind;   // one copy per thread: each reads back its own store
+    // the prefix product travels with the slot's kind in its pad word (read back by the thread that wrote it)
+    if (on) fp_store_blk(prefix_ws, o * LN + comp, run, kind);
+    if (kind <= PK_CANCEL) {
+      F::mul(tmp, run, den);
+      run = tmp;
+    }
   }
   E inv;
   PAIR_T(tc1);
   F::inv(inv, run);
   PAIR_T(tc2);
-  // ---- backward: individual inverses and the sums (highest slot of the lane first)
-  for (uint32_t it = n_it; it-- > 0;) {
-    const uint32_t o = it * NLe + t;
-    const uint32_t kind = kind_ws[(size_t)o * LN + comp];
-    uint32_t f0 = 0, f1 = 0;
-    E pre;
-    if constexpr (first) {
-      const uint2 e = ent2[o];
-      f0 = e.x == ENTRY_EMPTY ? PF_EMPTY : (e.x >> 31) * PF_NEG;
-      f1 = e.y == ENTRY_EMPTY ? PF_EMPTY : (e.y >> 31) * PF_NEG;
-      uint32_t r0 = (f0 & PF_EMPTY) ? 0u : (e.x & 0x7fffffffu);
-      uint32_t r1 = (f1 & PF_EMPTY) ? 0u : (e.y & 0x7fffffffu);
-      if (dbg & 16u) { r0 = 2 * (o & 1023u); r1 = r0 + 1; }
-      fp_load(x1, src_rows + (size_t)r0 * AW + cw);
-      fp_load(x2, src_rows + (size_t)r1 * AW + cw);
-      fp_load(y1, src_rows + (size_t)r0 * AW + EW + cw);
-      fp_load(y2, src_rows + (size_t)r1 * AW + EW + cw);
-    } else {
-      f0 = fp_load_blk(x1, src_planes, o * LN + comp);
-      f1 = fp_load_blk(x2, src_planes + src_stride, o * LN + comp);
-      (void)fp_load_blk(y1, src_planes + 2 * src_stride, o * LN + comp);
-      (void)fp_load_blk(y2, src_planes + 3 * src_stride, o * LN + comp);
+  // ---- backward: individual inverses and the sums (highest slot of the wave first)
+  // piece `idx` of the LDS-DMA of iteration `it`: ROW_PIECES row pieces, then the 7 quads of the prefix product
+  constexpr uint32_t BWD_PIECES = ROW_PIECES + 7u;
+  auto issue_bwd_piece = [=](uint32_t it, uint32_t buf, uint32_t idx) __attribute__((always_inline)) {
+    if (idx < ROW_PIECES) issue_row_piece(it, buf, idx, std::false_type{});
+    else if (idx < BWD_PIECES) {
+      const uint32_t o = min(it * NLe + (lane_on ? t : t0w), S - 1u);
+      const uint32_t q = idx - ROW_PIECES;
+      glds16(prefix_ws + blk_index(o * LN + comp) + (size_t)q * 64, pre_img + q * 64u);
     }
-    if (!(dbg & 4u)) (void)fp_load_blk(pre, prefix_ws, o * LN + comp); else pre = x1;
-    PAIR_T(tl0);
+  };
+  auto issue_bwd = [=](uint32_t it, uint32_t buf) __attribute__((always_inline)) {
+    for (uint32_t idx = 0; idx < BWD_PIECES; ++idx) issue_bwd_piece(it, buf, idx);
+  };
+  wait_vm0();                                            // the forward sweep's own stores (prefix products, kinds) are complete
+  if constexpr (first) {
+    issue_entries(n_it - 1u, 0);
+    wait_vm0();
+    issue_entries(n_it > 1u ? n_it - 2u : 0u, 1);
+  }
+  issue_bwd(n_it - 1u, 0);
+  for (uint32_t n = 0; n < n_it; ++n) {
+    const uint32_t it = n_it - 1u - n;
+    const uint32_t o = it * NLe + t;
+    const bool on = lane_on && o < S;
+    uint32_t f0, f1;
+    E pre;
+    wait_vm0();
+    read_rows(n & 1u, std::false_type{}, f0, f1, x1, y1, x2, y2);
+    const uint32_t kflag = fp_from_lds(pre, pre_img + lane, 64u);
+    const uint32_t kind = on ? kflag : (uint32_t)PK_EMPTY;
+    wait_lgkm0();
+    const bool more = n + 1u < n_it;
+    if constexpr (first) { if (more) issue_entries(it >= 2u ? it - 2u : 0u, n & 1u); }
+    const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
     uint32_t out_flag = PF_EMPTY;
+    E num, ysave;
+    ysave = y1;
+    if (kind == PK_ADD) {
+      out_flag = f1 & PF_NEG;
+      F::sub(den, x2, x1);
+      fp_addsub<M>(num, y2, y1, !flip);         // y2 - y1  or  y2 + y1
+    } else if (kind == PK_DBL) {
+      // P1 == P2 as signed points, s1 y1 = s2 y2: lambda = (3 x^2 + a) / (2 s1 y1) = s1 lambda' with the denominator 2 y1 formed
+      // exactly as in the forward sweep (y1 + y2, or y1 - y2 when the flags differ); result (x3, s1 (lambda' (x1 - x3) - y1))
+      E a;
+      fp_addsub<M>(den, y1, y2, flip);
+      F::mul(tmp, x1, x1);
+      F::add(num, tmp, tmp); F::add(num, num, tmp);
+      C::coeff_a(a);
+      F::add(num, num, a);
+      out_flag = f0 & PF_NEG;
+    } else {
+      // cancellation, odd leftover, empty slot: denominator 1 -- the lane runs the same products and its inversion chain
+      // keeps its value (inv * 1)
+      F::one(den);
+      num = den;
+    }
+    // The five products of a slot run through ONE inlined multiplier (and one squarer) in a wave-uniform step loop; every
+    // result replaces an operand that is dead by then, which keeps the loop's live state at seven elements:
+    //   0: pre <- inv * pre  (= 1 / den)      1: inv <- inv * den        2: den <- num * pre  (= lambda)
+    //   3: x2 <- lambda^2 - x1 - x2 (= x3), num <- x1 - x3             4: y1 <- lambda * num -+ y1  (= y3')
+    // Every lane runs every step (lanes without a pair carry denominator 1 and drop the results).  The LDS-DMA of the next
+    // slot is issued in five portions, one ahead of every product: 35 DMA instructions in a row stall the wave for as long as
+    // the address path needs to take them (~300 cycles each for gathered rows).
+    {
+      E opa, opb, res;
+      constexpr uint32_t PER_STEP = (BWD_PIECES + 4u) / 5u;
+#pragma nounroll
+      for (int step = 0; step < 5; ++step) {
+        if (more) {
+          for (uint32_t u = 0; u < PER_STEP; ++u) issue_bwd_piece(it - 1u, (n + 1u) & 1u, (uint32_t)step * PER_STEP + u);
+        }
+        switch (step) {
+          case 0: opa = inv; opb = pre; break;
+          case 1: opa = inv; opb = den; break;
+          case 2: opa = num; opb = pre; break;
+          case 3: opa = den; opb = den; break;
+          default: opa = den; opb = num; break;
+        }
+        if constexpr (has_sqr<F>::value) {
+          if (step == 3) F::sqr(res, opa); else F::mul(res, opa, opb);
+        } else {
+          F::mul(res, opa, opb);
+        }
+        switch (step) {
+          case 0: pre = res; break;
+          case 1: inv = res; break;
+          case 2: den = res; break;
+          case 3:
+            F::sub(res, res, x1);
+            F::sub(x2, res, x2);
+            F::sub(num, x1, x2);
+            break;
+          default:
+            fp_addsub<M>(y1, res, y1, !(kind == PK_ADD && flip));
+            break;
+        }
+      }
+    }
     if (kind == PK_SINGLE) {                    // odd leftover: copy, the sign travels in the flag
       out_flag = f0 & PF_NEG;
       x2 = x1;
-    } else if (kind != PK_EMPTY) {
-      E num;
-      const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
-      out_flag = f1 & PF_NEG;
-      if (kind == PK_ADD) {
-        F::sub(den, x2, x1);
-        fp_addsub<M>(num, y2, y1, !flip);       // y2 - y1  or  y2 + y1
-      } else if (kind == PK_DBL) {
-        // P1 == P2 as signed points, s1 y1 = s2 y2: lambda = (3 x^2 + a) / (2 s1 y1) = s1 lambda' with the denominator 2 y1 formed
-        // exactly as in the forward sweep (y1 + y2, or y1 - y2 when the flags differ); result (x3, s1 (lambda' (x1 - x3) - y1))
-        E a;
-        fp_addsub<M>(den, y1, y2, flip);
-        F::mul(tmp, x1, x1);
-        F::add(num, tmp, tmp); F::add(num, num, tmp);
-        C::coeff_a(a);
-        F::add(num, num, a);
-        out_flag = f0 & PF_NEG;
-      } else {                                  // cancellation: the slot only takes part in the inversion chain (denominator 1)
-        F::one(den);
-        num = den;
-      }
-      PAIR_T(tl1);
-      PAIR_SUM(sum_loads, tl0, tl1);
-      // The five products of a slot run through ONE inlined multiplier (and one squarer) in a wave-uniform step loop; every
-      // result replaces an operand that is dead by then, which keeps the loop's live state at seven elements:
-      //   0: pre <- inv * pre  (= 1 / den)      1: inv <- inv * den        2: den <- num * pre  (= lambda)
-      //   3: x2 <- lambda^2 - x1 - x2 (= x3), num <- x1 - x3             4: y1 <- lambda * num -+ y1  (= y3')
-      {
-        E opa, opb, res;
-        PAIR_T(ta);
-#pragma nounroll
-        for (int step = (dbg & 32u) ? 4 : 0; step < 5; ++step) {
-          switch (step) {
-            case 0: opa = inv; opb = pre; break;
-            case 1: opa = inv; opb = den; break;
-            case 2: opa = num; opb = pre; break;
-            case 3: opa = den; opb = den; break;
-            default: opa = den; opb = num; break;
-          }
-          if constexpr (has_sqr<F>::value) {
-            if (step == 3) F::sqr(res, opa); else F::mul(res, opa, opb);
-          } else {
-            F::mul(res, opa, opb);
-          }
-          switch (step) {
-            case 0: pre = res; break;
-            case 1: inv = res; break;
-            case 2: den = res; break;
-            case 3:
-              F::sub(res, res, x1);
-              F::sub(x2, res, x2);
-              F::sub(num, x1, x2);
-              break;
-            default:
-              fp_addsub<M>(y1, res, y1, !(kind == PK_ADD && flip));
-              break;
-          }
-        }
-        PAIR_T(tb);
-        PAIR_SUM(sum_steps, ta, tb);
-      }
+      y1 = ysave;
+    }
+    {
       if (kind == PK_CANCEL) {                  // P + (-P): emit D, remember to take it out of the bucket again
         fp_load(x2, gen + cw);
         fp_load(y1, gen + EW + cw);
@@ -747,23 +875,22 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       }
     }
     // result (x2, y1) with out_flag (an empty slot only needs its flag; the coordinates written with it are never used)
-    if (dbg & 2u) {
-      if (x2.l[0] == 0x12345u && y1.l[3] == 0x777u) kind_ws[0] = 1;   // keep the values alive
-    } else if constexpr (last) {
-      uint32_t* dst = out_rows + (size_t)o * AW;
-      fp_store_flag(dst + cw, x2, out_flag);
-      fp_store(dst + EW + cw, y1);
-      if (comp == 0) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : (o | ((out_flag & PF_NEG) ? 0x80000000u : 0u));
-    } else {
-      const uint32_t j = (o >> 1) * LN + comp;
-      uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
-      fp_store_blk(px, j, x2, out_flag);
-      fp_store_blk(px + 2 * out_stride, j, y1, 0u);
+    if (on) {
+      if constexpr (last) {
+        uint32_t* dst = out_rows + (size_t)o * AW;
+        fp_store_flag(dst + cw, x2, out_flag);
+        fp_store(dst + EW + cw, y1);
+        if (comp == 0) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : (o | ((out_flag & PF_NEG) ? 0x80000000u : 0u));
+      } else {
+        const uint32_t j = (o >> 1) * LN + comp;
+        uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
+        fp_store_blk(px, j, x2, out_flag);
+        fp_store_blk(px + 2 * out_stride, j, y1, 0u);
+      }
     }
   }
   PAIR_T(tc3);
   PAIR_ACC(0, tc0, tc1); PAIR_ACC(1, tc1, tc2); PAIR_ACC(2, tc2, tc3); PAIR_ACC(3, 0ull, 1ull);
-  PAIR_ACC(5, 0ull, sum_steps); PAIR_ACC(6, 0ull, sum_loads);
 }
 
 template <class C>

@@ -36,7 +36,6 @@ struct mnt753_bases {
   uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;
   // pairing levels (batched affine additions ahead of the accumulate): grow-only buffers
   uint32_t *d_pair_ws = nullptr, *d_fix = nullptr, *d_gen = nullptr;   // prefix products, cancellation counts per bucket, the stand-in point D
-  uint8_t* d_pair_kind = nullptr;                                       // kind of every slot of the level in flight
   uint32_t *d_pairpts[2] = {nullptr, nullptr}, *d_sorted2 = nullptr;    // rows of the levels (ping-pong), entry list of the last level
   size_t pair_cap = 0;   // level-1 slots the pairing buffers hold
   size_t pair_buckets = 0;   // buckets d_fix holds

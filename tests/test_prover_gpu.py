@@ -78,6 +78,22 @@ def test_reference_driver_unchanged(gpu, curve, tmp_path):
     assert filecmp.cmp(out, expected, shallow=False)
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+def test_resident_parameters_batch_mode(gpu, curve, tmp_path):
+    """main_hip proves several (input, output) pairs against parameters that stay resident on the GPU (window tables,
+    workspaces, evaluation domain): the reference pays its 0.4-9 s parameter load per process (main.cpp:196-201)."""
+    params, inp, expected = G.e2e_paths(curve)
+    o1, o2, o3 = (str(tmp_path / f"proof{k}.bin") for k in range(3))
+    r = subprocess.run([EXE, NAME[curve], "compute", params, inp, o1, inp, o2, inp, o3], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("Total time from input to output") == 3 and r.stdout.count("load params") == 1
+    for o in (o1, o2, o3):
+        assert filecmp.cmp(o, expected, shallow=False)
+    r = subprocess.run([EXE, NAME[curve], "compute", params, inp, o1, "--repeat", "2", "--ref-order"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count("Total time from input to output") == 2
+    assert filecmp.cmp(o1, expected, shallow=False)
+
+
 def test_params_header_is_validated(gpu, tmp_path):
     params, inp, _ = G.e2e_paths(0)
     raw = bytearray(open(params, "rb").read())
