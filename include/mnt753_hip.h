@@ -54,6 +54,18 @@ extern "C" {
 /* ---- lifecycle ------------------------------------------------------------------------------ */
 /* replaces B::init_public_params (prover_reference_functions.hpp:25).  device = HIP device ordinal. */
 int mnt753_init(int device);
+/* Several GPUs in one process: logical devices 0 .. n-1 = HIP devices 0 .. n-1.  A base set, a domain
+ * or a buffer lives on the device that is current for the calling thread when it is created (mnt753_set_device; device 0
+ * after initialisation, also in new threads); entry points that take a base set run on that set's device whatever the
+ * current one is.  The reference shards an MSM over OpenMP threads as contiguous slices and sums the partial results
+ * serially (depends/libff/libff/algebra/scalar_multiplication/multiexp.tcc:417-440); the wrapper classes do the same over
+ * devices: one base set per device and slice, the scalar slices copied device 0 -> device g (mnt753_copy_peer, xGMI), one
+ * projective point back per device, folded on the host in rank order with mnt753_point_add.
+ * MNT753_SHARE_DEVICE=1 (development) maps the logical devices onto however many are visible. */
+int mnt753_init_devices(int n_devices);
+int mnt753_device_count(void);
+int mnt753_set_device(int logical_device);
+int mnt753_copy_peer(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes);
 const char* mnt753_last_error(void);
 /* number of words (uint64) of one element / point of the given kind */
 size_t mnt753_affine_words(int curve, int group);      /* 24, 48 (MNT4753 G2) or 72 (MNT6753 G2) */

@@ -98,6 +98,11 @@ public:
   // ---- extensions (not in the reference wrapper) -------------------------------------------------
   // the whole of compute_H<B> in one device-resident call (overwrites ca, cb, cc like the reference)
   static vector_Fr *compute_H_fused(evaluation_domain *domain, vector_Fr *ca, vector_Fr *cb, vector_Fr *cc);
+  // Number of GPUs of this node the parameters are sharded over (call before init_public_params; default 1, or the value of
+  // the environment variable MNT753_GPUS).  Every vector_G1 / vector_G2 is cut into contiguous slices, one per device, exactly
+  // as libff cuts an MSM over OpenMP threads (multiexp.tcc:417-431); multiexp_G1 / multiexp_G2 run the slices concurrently
+  // and fold the partial results in rank order (multiexp.tcc:433-438).  The FFTs stay on device 0.
+  static void use_devices(int n);
   // raw access for tests / tools
   static const uint64_t *G1_words(const G1 *a);
   static const uint64_t *G2_words(const G2 *a);

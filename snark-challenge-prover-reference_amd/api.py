@@ -33,6 +33,10 @@ def lib():
     u64p, vp, sz, i = C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t, C.c_int
     sig = {
         "mnt753_init": (i, [i]),
+        "mnt753_init_devices": (i, [i]),
+        "mnt753_device_count": (i, []),
+        "mnt753_set_device": (i, [i]),
+        "mnt753_copy_peer": (i, [i, vp, i, vp, sz]),
         "mnt753_last_error": (C.c_char_p, []),
         "mnt753_affine_words": (sz, [i, i]),
         "mnt753_projective_words": (sz, [i, i]),

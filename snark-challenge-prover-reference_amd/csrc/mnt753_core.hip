@@ -13,10 +13,8 @@
 namespace mnt753 {
 namespace {
 thread_local std::string t_last_error;
-bool g_ready = false;
-int g_device = -1;
 // persistent staging for mnt753_load_file_to_device: creating a stream costs ~8 ms and pinning 32 MB a few more, so
-// they are made once in mnt753_init (outside any timed region) and reused under a mutex
+// they are made once per device at initialisation (outside any timed region) and reused under a mutex
 struct IoStaging {
   static constexpr size_t CHUNK = (size_t)16 << 20;
   std::mutex mu;
@@ -24,7 +22,49 @@ struct IoStaging {
   void* buf[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
   bool ok = false;
-} g_io;
+};
+// Logical devices 0 .. g_ndev-1 of this process.  mnt753_init(d) makes physical device d logical device 0 (the single-GPU
+// contract of the reference wrapper); mnt753_init_devices(n) maps logical i to physical i -- or, with MNT753_SHARE_DEVICE=1
+// (development: exercising the sharded path on a one-GPU box), to physical i % (visible devices).
+constexpr int MAX_DEVICES = 16;
+struct DevState { int phys = -1; bool ready = false; IoStaging io; };
+DevState g_devs[MAX_DEVICES];
+int g_ndev = 0;
+thread_local int t_cur_dev = 0;   // logical device the calling thread works on (mnt753_set_device)
+
+int init_one(int logical, int phys) {
+  HIP_TRY(hipSetDevice(phys));
+  HIP_TRY(hipFree(nullptr));
+  // Keep scratch resident.  The 512-register point-arithmetic kernels spill a few hundred bytes (G1 reduction kernels)
+  // to a few KB (Fq2/Fq3) per lane; ROCr sizes a dispatch's scratch for every wave slot of the device, and a dispatch
+  // above the queue's scratch threshold falls back to "use-once" scratch -- a host round trip per launch (~90 us
+  // measured here) that also keeps independent streams from overlapping.  Raise the threshold to the device maximum.
+  {
+    size_t smax = 0, scur = 0;
+    if (hipDeviceGetLimit(&smax, hipExtLimitScratchMax) == hipSuccess && hipDeviceGetLimit(&scur, hipExtLimitScratchCurrent) == hipSuccess &&
+        smax > scur) {
+      size_t want = smax;
+      if (const char* e = getenv("MNT753_SCRATCH_LIMIT_MB")) want = (size_t)atoll(e) << 20;
+      if (want > smax) want = smax;
+      if (want > scur) (void)hipDeviceSetLimit(hipExtLimitScratchCurrent, want);
+    }
+    if (getenv("MNT753_VERBOSE")) {
+      size_t now = 0; (void)hipDeviceGetLimit(&now, hipExtLimitScratchCurrent);
+      fprintf(stderr, "mnt753: device %d (physical %d): scratch limit max %zu MB, was %zu MB, now %zu MB\n", logical, phys, smax >> 20, scur >> 20, now >> 20);
+    }
+    (void)hipGetLastError();
+  }
+  DevState& d = g_devs[logical];
+  d.phys = phys;
+  if (!d.io.ok) {
+    bool ok = hipStreamCreateWithFlags(&d.io.stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+      ok = hipHostMalloc(&d.io.buf[k], IoStaging::CHUNK) == hipSuccess && hipEventCreateWithFlags(&d.io.done[k], hipEventDisableTiming) == hipSuccess;
+    d.io.ok = ok;
+  }
+  d.ready = true;
+  return 0;
+}
 }  // namespace
 
 int set_error(int code, const char* msg) {
@@ -38,9 +78,11 @@ int set_hip_error(hipError_t e, const char* what, const char* file, int line) {
   return e == hipErrorOutOfMemory ? MNT753_ENOMEM : MNT753_EHIP;
 }
 int require_device() {
-  if (!g_ready) return set_error(MNT753_ENODEV, "no HIP device: call mnt753_init() on a machine with an MI355X (there is no CPU fallback)");
+  if (g_ndev == 0 || !g_devs[t_cur_dev < g_ndev ? t_cur_dev : 0].ready)
+    return set_error(MNT753_ENODEV, "no HIP device: call mnt753_init() on a machine with an MI355X (there is no CPU fallback)");
   return 0;
 }
+int current_physical_device() { return g_ndev ? g_devs[t_cur_dev < g_ndev ? t_cur_dev : 0].phys : -1; }
 }  // namespace mnt753
 
 using namespace mnt753;
@@ -95,39 +137,59 @@ int mnt753_init(int device) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
-    g_ready = false;
+    g_ndev = 0;
     return set_error(MNT753_ENODEV, "mnt753_init: no HIP device visible");
   }
   if (device < 0 || device >= count) return set_error(MNT753_EINVAL, "mnt753_init: device ordinal out of range");
-  HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipFree(nullptr));
-  // Keep scratch resident.  The 512-register point-arithmetic kernels spill a few hundred bytes (G1 reduction kernels)
-  // to a few KB (Fq2/Fq3) per lane; ROCr sizes a dispatch's scratch for every wave slot of the device, and a dispatch
-  // above the queue's scratch threshold falls back to "use-once" scratch -- a host round trip per launch (~90 us
-  // measured here) that also keeps independent streams from overlapping.  Raise the threshold to the device maximum.
-  {
-    size_t smax = 0, scur = 0;
-    if (hipDeviceGetLimit(&smax, hipExtLimitScratchMax) == hipSuccess && hipDeviceGetLimit(&scur, hipExtLimitScratchCurrent) == hipSuccess &&
-        smax > scur) {
-      size_t want = smax;
-      if (const char* e = getenv("MNT753_SCRATCH_LIMIT_MB")) want = (size_t)atoll(e) << 20;
-      if (want > smax) want = smax;
-      if (want > scur) (void)hipDeviceSetLimit(hipExtLimitScratchCurrent, want);
-    }
-    if (getenv("MNT753_VERBOSE")) {
-      size_t now = 0; (void)hipDeviceGetLimit(&now, hipExtLimitScratchCurrent);
-      fprintf(stderr, "mnt753: scratch limit max %zu MB, was %zu MB, now %zu MB\n", smax >> 20, scur >> 20, now >> 20);
+  if (int rc = init_one(0, device)) return rc;
+  if (g_ndev < 1) g_ndev = 1;
+  t_cur_dev = 0;
+  return 0;
+}
+
+int mnt753_init_devices(int n_devices) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_ndev = 0;
+    return set_error(MNT753_ENODEV, "mnt753_init_devices: no HIP device visible");
+  }
+  const char* sh = getenv("MNT753_SHARE_DEVICE");
+  const bool share = sh && atoi(sh) != 0;
+  if (n_devices < 1 || n_devices > MAX_DEVICES || (!share && n_devices > count))
+    return set_error(MNT753_EINVAL, "mnt753_init_devices: more devices requested than visible (MNT753_SHARE_DEVICE=1 maps them onto the visible ones)");
+  for (int i = 0; i < n_devices; ++i)
+    if (int rc = init_one(i, share ? i % count : i)) return rc;
+  // peer access for the scalar slices (device 0 -> the others); failing to enable it only makes hipMemcpyPeer stage through the host
+  for (int i = 1; i < n_devices; ++i) {
+    if (g_devs[i].phys == g_devs[0].phys) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, g_devs[i].phys, g_devs[0].phys) == hipSuccess && can) {
+      (void)hipSetDevice(g_devs[i].phys);
+      (void)hipDeviceEnablePeerAccess(g_devs[0].phys, 0);
     }
     (void)hipGetLastError();
   }
-  g_device = device;
-  if (!g_io.ok) {
-    bool ok = hipStreamCreateWithFlags(&g_io.stream, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 2 && ok; ++k)
-      ok = hipHostMalloc(&g_io.buf[k], IoStaging::CHUNK) == hipSuccess && hipEventCreateWithFlags(&g_io.done[k], hipEventDisableTiming) == hipSuccess;
-    g_io.ok = ok;
-  }
-  g_ready = true;
+  g_ndev = n_devices;
+  t_cur_dev = 0;
+  HIP_TRY(hipSetDevice(g_devs[0].phys));
+  return 0;
+}
+
+int mnt753_device_count(void) { return g_ndev; }
+
+int mnt753_set_device(int logical) {
+  if (logical < 0 || logical >= g_ndev || !g_devs[logical].ready) return set_error(MNT753_EINVAL, "mnt753_set_device: not an initialised device");
+  t_cur_dev = logical;
+  HIP_TRY(hipSetDevice(g_devs[logical].phys));
+  return 0;
+}
+
+int mnt753_copy_peer(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes) {
+  if (dst_device < 0 || dst_device >= g_ndev || src_device < 0 || src_device >= g_ndev) return set_error(MNT753_EINVAL, "copy_peer: bad device");
+  if (bytes && (!dev_dst || !dev_src)) return set_error(MNT753_EINVAL, "copy_peer: null");
+  if (g_devs[dst_device].phys == g_devs[src_device].phys) HIP_TRY(hipMemcpy(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice));
+  else HIP_TRY(hipMemcpyPeer(dev_dst, g_devs[dst_device].phys, dev_src, g_devs[src_device].phys, bytes));
   return 0;
 }
 
@@ -183,7 +245,8 @@ int mnt753_dev_memset(void* dev_dst, int value, size_t bytes) {
 int mnt753_load_file_to_device(const char* path, size_t file_offset, size_t bytes, void* dev_dst) {
   if (int rc = require_device()) return rc;
   if (!path || (bytes && !dev_dst)) return set_error(MNT753_EINVAL, "load_file_to_device: null argument");
-  HIP_TRY(hipSetDevice(g_device));   // may be called from a thread that has not touched the device yet
+  IoStaging& g_io = g_devs[t_cur_dev < g_ndev ? t_cur_dev : 0].io;
+  HIP_TRY(hipSetDevice(current_physical_device()));   // may be called from a thread that has not touched the device yet
   FILE* f = fopen(path, "rb");
   if (!f) return set_error(MNT753_EINVAL, "load_file_to_device: cannot open file");
   if (fseeko(f, (off_t)file_offset, SEEK_SET) != 0) { fclose(f); return set_error(MNT753_EINVAL, "load_file_to_device: seek failed"); }

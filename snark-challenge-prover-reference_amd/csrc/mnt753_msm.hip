@@ -18,6 +18,12 @@ namespace {
 // MSM streams run at the lowest priority the device offers: an MSM is hundreds of milliseconds of throughput work,
 // and short kernels on the default stream (the NTTs of compute_H, launched while MSMs are in flight) should be
 // scheduled ahead of its remaining workgroups.
+// every entry point that takes a base set runs on the set's device and puts the thread back on its own afterwards
+struct OnDevice {
+  int back;
+  explicit OnDevice(int dev) : back(current_physical_device()) { if (dev != back) (void)hipSetDevice(dev); else back = -1; }
+  ~OnDevice() { if (back >= 0) (void)hipSetDevice(back); }
+};
 hipError_t create_msm_stream(hipStream_t* s) {
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
@@ -34,6 +40,7 @@ int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_dev
   mnt753_bases* b = new (std::nothrow) mnt753_bases();
   if (!b) return set_error(MNT753_ENOMEM, "bases_create: host allocation failed");
   b->curve = curve; b->group = group; b->n = n;
+  b->device = current_physical_device();
   int rc;
   if (curve == MNT753_CURVE_MNT4753) rc = group == MNT753_G1 ? bases_create_mnt4g1(b, affine, on_device, n) : bases_create_mnt4g2(b, affine, on_device, n);
   else rc = group == MNT753_G1 ? bases_create_mnt6g1(b, affine, on_device, n) : bases_create_mnt6g2(b, affine, on_device, n);
@@ -48,6 +55,7 @@ int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_dev
 
 int mnt753_bases_free(mnt753_bases* b) {
   if (!b) return 0;
+  OnDevice on(b->device);
   if (b->pending && b->pending_n) (void)hipStreamSynchronize(b->pending_stream);   // never free buffers under a running MSM
   msm_free_workspace(b);
   if (b->d_aff) (void)hipFree(b->d_aff);
@@ -66,6 +74,7 @@ int mnt753_msm(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int
   if (!b || !out_projective || (n && !scalars)) return set_error(MNT753_EINVAL, "msm: null argument");
   if (base_offset + n > b->n) return set_error(MNT753_EINVAL, "msm: base_offset + n exceeds the base set");
   if (int rc = require_device()) return rc;
+  OnDevice on(b->device);
   hipStream_t st = (hipStream_t)stream;
   if (b->curve == MNT753_CURVE_MNT4753)
     return b->group == MNT753_G1 ? msm_mnt4g1(b, base_offset, scalars, scalars_on_device, n, out_projective, st)
@@ -79,6 +88,7 @@ int mnt753_msm_start(mnt753_bases* b, size_t base_offset, const uint64_t* scalar
   if (!b || (n && !scalars)) return set_error(MNT753_EINVAL, "msm_start: null argument");
   if (base_offset + n > b->n) return set_error(MNT753_EINVAL, "msm_start: base_offset + n exceeds the base set");
   if (int rc = require_device()) return rc;
+  OnDevice on(b->device);
   hipStream_t st = (hipStream_t)stream;
   if (!st) {
     // the base set's own non-blocking stream, ordered after everything already enqueued on the default stream
@@ -103,6 +113,7 @@ int mnt753_msm_start(mnt753_bases* b, size_t base_offset, const uint64_t* scalar
 int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective) {
   if (!b || !out_projective) return set_error(MNT753_EINVAL, "msm_finish: null argument");
   if (int rc = require_device()) return rc;
+  OnDevice on(b->device);
   if (b->curve == MNT753_CURVE_MNT4753)
     return b->group == MNT753_G1 ? msm_finish_mnt4g1(b, out_projective) : msm_finish_mnt4g2(b, out_projective);
   return b->group == MNT753_G1 ? msm_finish_mnt6g1(b, out_projective) : msm_finish_mnt6g2(b, out_projective);

@@ -21,6 +21,7 @@ struct MsmPlan {
 
 struct mnt753_bases {
   int curve, group;
+  int device = 0;              // physical HIP device the set lives on (the creating thread's current device)
   size_t n;
   uint32_t* d_aff = nullptr;   // device affine, internal form: pre_W * n rows when the window table is built (row w*n + i = 2^(c w) P_i)
   int pre_c = 0, pre_W = 0;    // window bits / windows of the precomputed table (0 = no table)

@@ -25,6 +25,7 @@
 static bool g_fused_h = true;
 static bool g_quiet = false;
 static bool g_h_first = true;
+static int g_gpus = 0;   // --gpus N: parameter vectors sharded over N devices of this node (0: MNT753_GPUS or 1)
 
 typedef std::chrono::steady_clock clk;
 static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
@@ -128,6 +129,7 @@ void prove_one(typename B::groth16_params* params, const char* input_path, const
 // jobs: (input, output) pairs; all proved against the same resident parameters
 template <typename B>
 void run_prover(const char* params_path, const std::vector<std::pair<std::string, std::string>>& jobs) {
+  if (g_gpus > 0) B::use_devices(g_gpus);
   B::init_public_params();
   auto t0 = clk::now();
   auto params = B::read_params(params_path);
@@ -145,7 +147,7 @@ void run_prover(const char* params_path, const std::vector<std::pair<std::string
 int main(int argc, char** argv) {
   setbuf(stdout, NULL);
   if (argc < 6) {
-    fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--unfused-h] [--ref-order] [--quiet]\n"
+    fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--unfused-h] [--ref-order] [--quiet]\n"
                     "  further (input, output) pairs and --repeat prove against the parameters that are already resident on the GPU\n", argv[0]);
     return 2;
   }
@@ -154,6 +156,7 @@ int main(int argc, char** argv) {
   int repeat = 1;
   for (int i = 6; i < argc; ++i) {
     if (!strcmp(argv[i], "--repeat") && i + 1 < argc) { repeat = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { g_gpus = atoi(argv[++i]); continue; }
     if (argv[i][0] != '-' && i + 1 < argc && argv[i + 1][0] != '-') { jobs.emplace_back(argv[i], argv[i + 1]); ++i; continue; }
     if (!strcmp(argv[i], "--fused-h")) g_fused_h = true;
     else if (!strcmp(argv[i], "--unfused-h")) g_fused_h = false;

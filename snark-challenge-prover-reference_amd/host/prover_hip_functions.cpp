@@ -6,7 +6,9 @@
 #include <sys/stat.h>
 
 #include <condition_variable>
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -49,6 +51,20 @@ struct BaseSetHolder {
   mnt753_bases* h = nullptr;
   ~BaseSetHolder() { if (h) mnt753_bases_free(h); }
 };
+static int g_n_devices = 0;   // 0: not chosen yet (init_public_params reads MNT753_GPUS, default 1)
+// A parameter vector cut into contiguous slices, slice g resident on logical device g (multiexp.tcc:417-431: one = n / chunks,
+// the last slice takes the remainder).  One device = one slice = the single-GPU wrapper.
+struct ShardedBases {
+  struct Part {
+    std::shared_ptr<BaseSetHolder> set;
+    size_t lo = 0, hi = 0;
+    std::shared_ptr<DeviceBuffer> scalars;   // staging for the scalar slice on devices other than 0 (grow-only)
+  };
+  std::vector<Part> parts;
+  size_t n = 0;
+};
+// one MSM in flight on every slice of a sharded vector
+struct PendingMsm { std::vector<std::shared_ptr<BaseSetHolder>> sets; };
 struct DomainHolder {
   mnt753_domain* h = nullptr;
   ~DomainHolder() { if (h) mnt753_domain_free(h); }
@@ -64,8 +80,8 @@ using namespace mnt753_hip_detail;
 template <int CURVE> struct mnt753_hip_impl<CURVE>::evaluation_domain { std::shared_ptr<DomainHolder> data; };
 template <int CURVE> struct mnt753_hip_impl<CURVE>::field { uint64_t data[12]; };
 // G1 / G2 returned by multiexp_* are lazy: the MSM is in flight on its base set's stream until the value is first used
-template <int CURVE> struct mnt753_hip_impl<CURVE>::G1 { uint64_t data[36]; std::shared_ptr<BaseSetHolder> pending; };
-template <int CURVE> struct mnt753_hip_impl<CURVE>::G2 { uint64_t data[108]; std::shared_ptr<BaseSetHolder> pending; };  // 72 used on MNT4753, 108 on MNT6753
+template <int CURVE> struct mnt753_hip_impl<CURVE>::G1 { uint64_t data[36]; std::shared_ptr<PendingMsm> pending; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::G2 { uint64_t data[108]; std::shared_ptr<PendingMsm> pending; };  // 72 used on MNT4753, 108 on MNT6753
 template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
   std::shared_ptr<DeviceBuffer> data;
   size_t size;     // elements in the underlying buffer
@@ -77,8 +93,8 @@ template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
     return reinterpret_cast<uint64_t*>(data->ptr) + 12 * offset;
   }
 };
-template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G1 { std::shared_ptr<BaseSetHolder> data; };
-template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G2 { std::shared_ptr<BaseSetHolder> data; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G1 { std::shared_ptr<ShardedBases> data; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G2 { std::shared_ptr<ShardedBases> data; };
 
 // params file: u64 d, u64 m, A[m+1] G1, B1[m+1] G1, B2[m+1] G2, L[m-1] G1, H[d] G1
 // (libsnark/generate_parameters.cpp:60-85, reader prover_reference_functions.cpp:86-116)
@@ -86,7 +102,7 @@ template <int CURVE>
 class mnt753_hip_impl<CURVE>::groth16_params {
 public:
   size_t d = 0, m = 0;
-  std::shared_ptr<BaseSetHolder> A, B1, L, H, B2;
+  std::shared_ptr<ShardedBases> A, B1, L, H, B2;
   explicit groth16_params(const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) throw std::runtime_error(std::string("cannot open params file ") + path);
@@ -109,12 +125,24 @@ public:
                                  ", expected " + std::to_string(expect) + " bytes, found " + std::to_string((unsigned long long)st.st_size) + "): " + path);
       }
     }
+    const int n_dev = std::max(1, mnt753_device_count());
     auto load = [&](int group, size_t words, size_t n) {
       std::vector<uint64_t> host(words * n);
       read_exact(f, host.data(), host.size() * 8, path);
-      auto h = std::make_shared<BaseSetHolder>();
-      check(mnt753_bases_create(CURVE, group, host.data(), 0, n, &h->h), "mnt753_bases_create");
-      return h;
+      auto sb = std::make_shared<ShardedBases>();
+      sb->n = n;
+      const size_t one = n / (size_t)n_dev;
+      for (int g = 0; g < n_dev; ++g) {
+        ShardedBases::Part part;
+        part.lo = (size_t)g * one;
+        part.hi = g == n_dev - 1 ? n : (size_t)(g + 1) * one;
+        part.set = std::make_shared<BaseSetHolder>();
+        if (n_dev > 1) check(mnt753_set_device(g), "mnt753_set_device");
+        check(mnt753_bases_create(CURVE, group, host.data() + words * part.lo, 0, part.hi - part.lo, &part.set->h), "mnt753_bases_create");
+        sb->parts.push_back(part);
+      }
+      if (n_dev > 1) check(mnt753_set_device(0), "mnt753_set_device");
+      return sb;
     };
     A = load(MNT753_G1, g1w, m + 1);
     B1 = load(MNT753_G1, g1w, m + 1);
@@ -174,18 +202,35 @@ public:
 
 #define HIP_B mnt753_hip_impl<CURVE>
 
-template <class P> static void resolve(P* p) {
-  if (p->pending) {
-    check(mnt753_msm_finish(p->pending->h, p->data), "mnt753_msm_finish");
-    p->pending.reset();
+// collect the partial results of the slices and fold them in rank order (multiexp.tcc:433-438: final = final + partial[i])
+template <int CURVE, int GROUP, class P> static void resolve_t(P* p) {
+  if (!p->pending) return;
+  bool have = false;
+  for (auto& set : p->pending->sets) {
+    uint64_t part[108];
+    check(mnt753_msm_finish(set->h, part), "mnt753_msm_finish");
+    if (!have) { memcpy(p->data, part, sizeof(uint64_t) * mnt753_projective_words(CURVE, GROUP)); have = true; }
+    else check(mnt753_point_add(CURVE, GROUP, p->data, part, p->data), "mnt753_point_add");
   }
+  if (!have) {   // an empty MSM: the identity (0 : 1 : 0)
+    uint64_t zero_aff[72] = {0};
+    check(mnt753_point_from_affine(CURVE, GROUP, zero_aff, p->data), "mnt753_point_from_affine");
+  }
+  p->pending.reset();
 }
+template <int CURVE> static void resolve(typename mnt753_hip_impl<CURVE>::G1* p) { resolve_t<CURVE, MNT753_G1>(p); }
+template <int CURVE> static void resolve(typename mnt753_hip_impl<CURVE>::G2* p) { resolve_t<CURVE, MNT753_G2>(p); }
 
-template <int CURVE> void HIP_B::init_public_params() { check(mnt753_init(0), "mnt753_init"); }
+template <int CURVE> void HIP_B::use_devices(int n) { g_n_devices = n < 1 ? 1 : n; }
+template <int CURVE> void HIP_B::init_public_params() {
+  if (g_n_devices == 0) { const char* e = getenv("MNT753_GPUS"); g_n_devices = e && atoi(e) > 0 ? atoi(e) : 1; }
+  if (g_n_devices > 1) check(mnt753_init_devices(g_n_devices), "mnt753_init_devices");
+  else check(mnt753_init(0), "mnt753_init");
+}
 
 template <int CURVE> void HIP_B::print_G1(G1* a) {
   uint64_t aff[24];
-  resolve(a);
+  resolve<CURVE>(a);
   check(mnt753_point_to_affine(CURVE, MNT753_G1, a->data, aff), "mnt753_point_to_affine");
   printf("G1 affine (Montgomery limbs, little-endian):\n x =");
   for (int i = 11; i >= 0; --i) printf(" %016llx", (unsigned long long)aff[i]);
@@ -196,7 +241,7 @@ template <int CURVE> void HIP_B::print_G1(G1* a) {
 template <int CURVE> void HIP_B::print_G2(G2* a) {
   const size_t w = mnt753_affine_words(CURVE, MNT753_G2);
   uint64_t aff[72];
-  resolve(a);
+  resolve<CURVE>(a);
   check(mnt753_point_to_affine(CURVE, MNT753_G2, a->data, aff), "mnt753_point_to_affine");
   printf("G2 affine (Montgomery limbs, little-endian), %zu coefficients:\n", w / 12);
   for (size_t k = 0; k < w / 12; ++k) {
@@ -226,13 +271,13 @@ template <int CURVE> typename HIP_B::evaluation_domain* HIP_B::get_evaluation_do
 
 template <int CURVE> typename HIP_B::G1* HIP_B::G1_add(G1* a, G1* b) {
   G1* r = new G1();
-  resolve(a); resolve(b);
+  resolve<CURVE>(a); resolve<CURVE>(b);
   check(mnt753_point_add(CURVE, MNT753_G1, a->data, b->data, r->data), "mnt753_point_add");
   return r;
 }
 template <int CURVE> typename HIP_B::G1* HIP_B::G1_scale(field* a, G1* b) {
   G1* r = new G1();
-  resolve(b);
+  resolve<CURVE>(b);
   check(mnt753_point_scale(CURVE, MNT753_G1, a->data, b->data, r->data), "mnt753_point_scale");
   return r;
 }
@@ -274,16 +319,36 @@ template <int CURVE> void HIP_B::domain_divide_by_Z_on_coset(evaluation_domain* 
 }
 template <int CURVE> size_t HIP_B::domain_get_m(evaluation_domain* domain) { return mnt753_domain_size(domain->data->h); }
 
+// sum_{i < length} scalars[i] * bases[i] over the slices of a sharded vector: slice g covers [lo_g, hi_g) of the bases, the
+// matching scalars are copied from device 0 to device g, every slice's MSM is enqueued on its own device and stream
+static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const uint64_t* scalars_dev0, size_t length, const char* what) {
+  auto pend = std::make_shared<PendingMsm>();
+  const int n_dev = (int)sb.parts.size();
+  for (int g = 0; g < n_dev; ++g) {
+    ShardedBases::Part& part = sb.parts[g];
+    const size_t lo = part.lo, hi = std::min(part.hi, length);
+    if (hi <= lo) continue;
+    const uint64_t* sc = scalars_dev0 + 12 * lo;
+    if (g > 0) {
+      if (n_dev > 1) check(mnt753_set_device(g), "mnt753_set_device");
+      if (!part.scalars || part.scalars->bytes < 96 * (hi - lo)) part.scalars = std::make_shared<DeviceBuffer>(96 * (part.hi - part.lo));
+      check(mnt753_copy_peer(g, part.scalars->ptr, 0, sc, 96 * (hi - lo)), "mnt753_copy_peer");
+      sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
+    }
+    check(mnt753_msm_start(part.set->h, 0, sc, 1, hi - lo, nullptr), what);
+    pend->sets.push_back(part.set);
+  }
+  if (n_dev > 1) check(mnt753_set_device(0), "mnt753_set_device");
+  return pend;
+}
 template <int CURVE> typename HIP_B::G1* HIP_B::multiexp_G1(vector_Fr* scalar_start, vector_G1* g_start, size_t length) {
   G1* r = new G1();
-  check(mnt753_msm_start(g_start->data->h, 0, scalar_start->ptr(), 1, length, nullptr), "mnt753_msm_start(G1)");
-  r->pending = g_start->data;
+  r->pending = start_sharded(*g_start->data, scalar_start->ptr(), length, "mnt753_msm_start(G1)");
   return r;
 }
 template <int CURVE> typename HIP_B::G2* HIP_B::multiexp_G2(vector_Fr* scalar_start, vector_G2* g_start, size_t length) {
   G2* r = new G2();
-  check(mnt753_msm_start(g_start->data->h, 0, scalar_start->ptr(), 1, length, nullptr), "mnt753_msm_start(G2)");
-  r->pending = g_start->data;
+  r->pending = start_sharded(*g_start->data, scalar_start->ptr(), length, "mnt753_msm_start(G2)");
   return r;
 }
 
@@ -313,8 +378,8 @@ template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_L(groth16_params* 
 template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_H(groth16_params* p) { return new vector_G1{p->H}; }
 template <int CURVE> typename HIP_B::vector_G2* HIP_B::params_B2(groth16_params* p) { return new vector_G2{p->B2}; }
 
-template <int CURVE> void HIP_B::delete_G1(G1* a) { if (a) resolve(a); delete a; }
-template <int CURVE> void HIP_B::delete_G2(G2* a) { if (a) resolve(a); delete a; }
+template <int CURVE> void HIP_B::delete_G1(G1* a) { if (a) resolve<CURVE>(a); delete a; }
+template <int CURVE> void HIP_B::delete_G2(G2* a) { if (a) resolve<CURVE>(a); delete a; }
 template <int CURVE> void HIP_B::delete_vector_Fr(vector_Fr* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_G1(vector_G1* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_G2(vector_G2* a) { delete a; }
@@ -326,7 +391,7 @@ template <int CURVE> void HIP_B::delete_evaluation_domain(evaluation_domain* a) 
 template <int CURVE> void HIP_B::groth16_output_write(G1* A, G2* B, G1* C, const char* output_path) {
   const size_t g2w = mnt753_affine_words(CURVE, MNT753_G2);
   uint64_t a[24], b[72], c[24];
-  resolve(A); resolve(B); resolve(C);
+  resolve<CURVE>(A); resolve<CURVE>(B); resolve<CURVE>(C);
   check(mnt753_point_to_affine(CURVE, MNT753_G1, A->data, a), "mnt753_point_to_affine(A)");
   check(mnt753_point_to_affine(CURVE, MNT753_G2, B->data, b), "mnt753_point_to_affine(B)");
   check(mnt753_point_to_affine(CURVE, MNT753_G1, C->data, c), "mnt753_point_to_affine(C)");
@@ -344,8 +409,8 @@ template <int CURVE> typename HIP_B::vector_Fr* HIP_B::compute_H_fused(evaluatio
   check(mnt753_compute_h(domain->data->h, ca->ptr(), cb->ptr(), cc->ptr(), reinterpret_cast<uint64_t*>(h->ptr), nullptr), "mnt753_compute_h");
   return new vector_Fr{h, m + 1, 0, nullptr};
 }
-template <int CURVE> const uint64_t* HIP_B::G1_words(const G1* a) { resolve(const_cast<G1*>(a)); return a->data; }
-template <int CURVE> const uint64_t* HIP_B::G2_words(const G2* a) { resolve(const_cast<G2*>(a)); return a->data; }
+template <int CURVE> const uint64_t* HIP_B::G1_words(const G1* a) { resolve<CURVE>(const_cast<G1*>(a)); return a->data; }
+template <int CURVE> const uint64_t* HIP_B::G2_words(const G2* a) { resolve<CURVE>(const_cast<G2*>(a)); return a->data; }
 
 template class mnt753_hip_impl<0>;
 template class mnt753_hip_impl<1>;

@@ -53,6 +53,7 @@ def test_no_cpu_fallback(pkg):
     assert L.mnt753_domain_create(0, 8, ctypes.byref(h)) == -2
     assert L.mnt753_vec_muleq(0, ctypes.c_void_p(8), ctypes.c_void_p(8), 1, None) == -2
     assert L.mnt753_load_file_to_device(b"/dev/null", 0, 0, None) == -2
+    assert L.mnt753_init_devices(2) == -2 and L.mnt753_device_count() == 0 and L.mnt753_set_device(0) == -1
     with pytest.raises(pkg.Mnt753Error):
         pkg.init(0)
 

@@ -94,6 +94,38 @@ def test_resident_parameters_batch_mode(gpu, curve, tmp_path):
     assert filecmp.cmp(o1, expected, shallow=False)
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("n_dev", [2, 3])
+def test_sharded_inside_the_boundary(gpu, curve, n_dev, tmp_path):
+    """main_hip --gpus N: ONE process, the five parameter vectors cut into N contiguous slices (multiexp.tcc:417-431), one base
+    set per device and slice, scalar slices copied device 0 -> device g, partial points folded in rank order -- B::multiexp_G1
+    itself shards.  On the one-GPU test box MNT753_SHARE_DEVICE=1 maps the logical devices onto the visible one (same code path
+    except that the peer copy is a local copy).  Reference proofs and a synthetic set whose vectors do not divide evenly."""
+    env = dict(os.environ, MNT753_SHARE_DEVICE="1")
+    params, inp, expected = G.e2e_paths(curve)
+    out = str(tmp_path / "proof.bin")
+    for flags in ([], ["--ref-order", "--unfused-h"]):
+        r = subprocess.run([EXE, NAME[curve], "compute", params, inp, out, "--gpus", str(n_dev)] + flags, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert filecmp.cmp(out, expected, shallow=False)
+    p2, i2 = str(tmp_path / "params"), str(tmp_path / "input")
+    synth_files.write_files(gpu, curve, 11 - curve, p2, i2)
+    o1, oN = str(tmp_path / "one.bin"), str(tmp_path / "many.bin")
+    assert subprocess.run([EXE, NAME[curve], "compute", p2, i2, o1], capture_output=True, text=True).returncode == 0
+    r = subprocess.run([EXE, NAME[curve], "compute", p2, i2, oN, "--gpus", str(n_dev), "--repeat", "2"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(o1, oN, shallow=False)
+
+
+def test_more_devices_than_visible_is_refused(gpu, tmp_path):
+    params, inp, _ = G.e2e_paths(0)
+    env = {k: v for k, v in os.environ.items() if k != "MNT753_SHARE_DEVICE"}
+    r = subprocess.run([EXE, "MNT4753", "compute", params, inp, str(tmp_path / "o"), "--gpus", "16"], capture_output=True, text=True, env=env)
+    import torch
+    if torch.cuda.device_count() < 16:
+        assert r.returncode == 1 and "more devices requested than visible" in r.stderr
+
+
 def test_params_header_is_validated(gpu, tmp_path):
     params, inp, _ = G.e2e_paths(0)
     raw = bytearray(open(params, "rb").read())
