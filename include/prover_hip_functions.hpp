@@ -103,6 +103,8 @@ public:
   // as libff cuts an MSM over OpenMP threads (multiexp.tcc:417-431); multiexp_G1 / multiexp_G2 run the slices concurrently
   // and fold the partial results in rank order (multiexp.tcc:433-438).  The FFTs stay on device 0.
   static void use_devices(int n);
+  // seconds the background loader of read_input needed until the whole input file was on the device (waits for it)
+  static double input_load_seconds(groth16_input *input);
   // raw access for tests / tools
   static const uint64_t *G1_words(const G1 *a);
   static const uint64_t *G2_words(const G2 *a);

@@ -86,7 +86,7 @@ def test_resident_parameters_batch_mode(gpu, curve, tmp_path):
     o1, o2, o3 = (str(tmp_path / f"proof{k}.bin") for k in range(3))
     r = subprocess.run([EXE, NAME[curve], "compute", params, inp, o1, inp, o2, inp, o3], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert r.stdout.count("Total time from input to output") == 3 and r.stdout.count("load params") == 1
+    assert r.stdout.count("Total time from input to output") == 3 and r.stdout.count("load params:") == 1
     for o in (o1, o2, o3):
         assert filecmp.cmp(o, expected, shallow=False)
     r = subprocess.run([EXE, NAME[curve], "compute", params, inp, o1, "--repeat", "2", "--ref-order"], capture_output=True, text=True)
