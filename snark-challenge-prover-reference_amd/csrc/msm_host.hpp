@@ -152,11 +152,13 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_edge_bucket, sizeof(uint32_t) * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_flags, sizeof(uint32_t) * 40));
-  HIP_TRY(hipMalloc(&b->d_part_a, sizeof(uint32_t) * PW * (size_t)p.n_chunks));
-  HIP_TRY(hipMalloc(&b->d_part_b, sizeof(uint32_t) * PW * ((size_t)p.n_chunks / 2 + (size_t)p.W + 4)));
-  HIP_TRY(hipMalloc(&b->d_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_chunks));
-  HIP_TRY(hipMalloc(&b->d_wire_out, sizeof(uint32_t) * 3 * wire_coord_words<C>() * (size_t)p.W));
-  HIP_TRY(hipHostMalloc(&b->h_wire_out, sizeof(uint32_t) * 3 * wire_coord_words<C>() * (size_t)p.W));
+  // bucket reduction by halving (k_reduce_step): A_1 .. A_k and the ping-pong halves of the trees, nb points each per bucket
+  // set; then the c points per set (T, G_0 .. G_{c-2}) the host combines
+  HIP_TRY(hipMalloc(&b->d_part_a, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
+  HIP_TRY(hipMalloc(&b->d_part_b, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
+  HIP_TRY(hipMalloc(&b->d_tmp, sizeof(uint32_t) * PW * (size_t)p.n_sets * (size_t)p.c));
+  HIP_TRY(hipMalloc(&b->d_wire_out, sizeof(uint32_t) * 3 * wire_coord_words<C>() * (size_t)p.n_sets * (size_t)p.c));
+  HIP_TRY(hipHostMalloc(&b->h_wire_out, sizeof(uint32_t) * 3 * wire_coord_words<C>() * (size_t)p.n_sets * (size_t)p.c));
   HIP_TRY(hipMalloc(&b->d_scalars_stage, 96 * n));
   b->ws_n = n;
   b->ws_plan = p;
@@ -228,15 +230,26 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   return 0;
 }
 
+// Host tail of an MSM.  Per bucket set the device hands over c points: T (the plain sum of the buckets) and G_0 .. G_{c-2}
+// (k_reduce_step); the set's value sum_b (b + 1) B[b] is  T + sum_l 2^l G_l  -- Horner from the top, c - 1 doublings and
+// additions.  Without the window table the W sets are the windows and a second Horner (c doublings per window) combines them;
+// with it there is one set and nothing left to do.
 template <class HC>
-void horner_host(const uint64_t* wire_pts, int W, int c, uint64_t* out) {
+void horner_host(const uint64_t* wire_pts, int n_sets, int c, uint64_t* out) {
   using P = host::HPoint<HC>;
   const int PWW = 36 * HC::F::DEG;
   P acc = P::zero();
-  for (int w = W - 1; w >= 0; --w) {
+  for (int w = n_sets - 1; w >= 0; --w) {
+    const uint64_t* pts = wire_pts + (size_t)w * c * PWW;
+    P g = P::zero();
+    for (int l = c - 2; l >= 0; --l) {
+      if (!g.is_zero()) g = g.dbl();
+      g = g.add(P::from_wire(pts + (size_t)(1 + l) * PWW));
+    }
+    g = g.add(P::from_wire(pts));
     if (!acc.is_zero())
       for (int k = 0; k < c; ++k) acc = acc.dbl();
-    acc = acc.add(P::from_wire(wire_pts + (size_t)w * PWW));
+    acc = acc.add(g);
   }
   acc.to_wire(out);
 }
@@ -427,27 +440,19 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
         hipLaunchKernelGGL((k_pair_fix<V>), dim3(blocks_for<typename V::F>(p.n_buckets)), dim3(256), 0, st, b->d_buckets, b->d_fix, b->d_gen, p.n_buckets);
     }
   }
-  if (mask & 4u)
-    hipLaunchKernelGGL((k_bucket_reduce<V>), dim3(blocks_for<typename V::F>(p.n_chunks)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,
-                       b->d_tmp, p.nb, p.L, p.n_chunks, p.c - 1);
-  else
-    hipLaunchKernelGGL((k_bucket_reduce<C>), dim3(blocks_for<typename C::F>(p.n_chunks)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a,
-                       b->d_tmp, p.nb, p.L, p.n_chunks, p.c - 1);
-  // tree: [W][n_in] -> [W][1]
-  const uint32_t NS = p.n_sets;   // bucket sets = points that survive the reduction
-  uint32_t n_in = p.nb / p.L;
-  uint32_t* cur = b->d_part_a;
-  uint32_t* nxt = b->d_part_b;
-  const uint32_t R = 2;   // log-depth: every level is one group addition deep
-  while (n_in > 1) {
-    uint32_t n_out = (n_in + R - 1) / R;
-    if (mask & 8u)
-      hipLaunchKernelGGL((k_tree_sum<V>), dim3(blocks_for<typename V::F>((uint64_t)NS * n_out)), dim3(256), 0, st, cur, nxt, NS, n_in, n_out, R);
-    else
-      hipLaunchKernelGGL((k_tree_sum<C>), dim3(blocks_for<typename C::F>((uint64_t)NS * n_out)), dim3(256), 0, st, cur, nxt, NS, n_in, n_out, R);
-    std::swap(cur, nxt);
-    n_in = n_out;
+  // bucket reduction: k = c - 1 halving steps (each one group addition deep), then the c points per bucket set for the host
+  {
+    const uint32_t k = (uint32_t)p.c - 1u, NS = p.n_sets;
+    for (uint32_t step = 0; step < k; ++step) {
+      const uint64_t items = (uint64_t)NS * red_items(k, step);
+      if (mask & 4u)
+        hipLaunchKernelGGL((k_reduce_step<V>), dim3(blocks_for<typename V::F>(items)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
+      else
+        hipLaunchKernelGGL((k_reduce_step<C>), dim3(blocks_for<typename C::F>(items)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
+    }
+    hipLaunchKernelGGL((k_reduce_collect<C>), dim3((NS * (k + 1u) + 63) / 64), dim3(64), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, b->d_tmp, NS, k);
   }
+  uint32_t* cur = b->d_tmp;
   *result = cur;
   return 0;
 }
@@ -506,11 +511,11 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
     else rc = point_stages<C, C>(p, n, st, d_aff, b, &cur);
     if (rc) return rc;
   }
-  const uint32_t NS = p.n_sets;
-  hipLaunchKernelGGL((k_points_to_wire<C>), dim3((NS + 63) / 64), dim3(64), 0, st, cur, b->d_wire_out, NS);
+  const uint32_t NS = p.n_sets, NP = NS * (uint32_t)p.c;   // c points per bucket set: T, G_0 .. G_{c-2}
+  hipLaunchKernelGGL((k_points_to_wire<C>), dim3((NP + 63) / 64), dim3(64), 0, st, cur, b->d_wire_out, NP);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[3], st));
-  HIP_TRY(hipMemcpyAsync(b->h_wire_out, b->d_wire_out, sizeof(uint64_t) * PWW * (size_t)NS, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(b->h_wire_out, b->d_wire_out, sizeof(uint64_t) * PWW * (size_t)NP, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(b->ev[4], st));
   b->pending_sets = (int)NS; b->pending_c = p.c;
   return 0;

@@ -16,8 +16,8 @@
 //                         distribution); whole buckets go straight to the bucket array, the first / last partial run of
 //                         each lane goes to an edge array
 //   k_edge_level_*        pointer-jumping sum of the edge pieces that belong to one bucket
-//   k_bucket_reduce       chunked running sums  sum_b (b+1)*B[b]
-//   k_tree_sum            sums the chunk results
+//   k_reduce_step         bucket reduction by halving: c - 1 launches, each one group addition deep (T and the G_l of
+//                         sum_b (b+1) B[b] = T + sum_l 2^l G_l); k_reduce_collect gathers the c points the host combines
 //   k_points_to_wire      -> wire form (projective, Montgomery R=2^768)
 //   host                  only without the window table (small sets): Horner over the window sums
 // The G2 instantiations of the point kernels run on lane-split extension fields (curve753.hip.h): 2 or 3 lanes per point.
@@ -987,89 +987,95 @@ __global__ void __launch_bounds__(256) k_edge_finish(const uint32_t* __restrict_
 }
 
 // ---- bucket reduction ------------------------------------------------------------------------------
-// One lane per (window, chunk of L buckets): out = sum_{j<L} (k0 + j + 1) * B[k0 + j], k0 = chunk * L.
-// Running sums give  acc = sum (j+1) B[k0+j]  and  run = sum B[k0+j];  k0*run is added by
-// double-and-add.  Every lane executes the same (2L + 2*kbits + 1)-step schedule, so the wave never
-// diverges on the step loop and the kernel has ONE pt_vm call site; run / acc / R live in a small
-// per-lane HBM workspace (3 points, ~1 KB of traffic per ~50 us group operation).
+// sum_b (b + 1) B[b] over nb = 2^k buckets by HALVING, every step one group addition deep:
+//     A_0 = B,   A_{l+1}[j] = A_l[2j] + A_l[2j+1],   G_l = sum of the odd-indexed elements of A_l        (l = 0 .. k-1)
+// A_k[0] = T is the plain sum and  sum_b b B[b] = sum_l 2^l G_l  (bit l of b is set exactly for the elements that sit at an
+// odd index of A_l), so the result is T + sum_l 2^l G_l -- a 19-step Horner over single points, done on the host by
+// msm_finish (k doublings + k additions, < 0.1 ms; one GPU lane would need milliseconds).  G_l is a tree sum of 2^(k-l-1)
+// elements; its first step reads A_l directly (A_l[4j+1] + A_l[4j+3]) in the SAME step that halves A_l, so tree l runs in
+// steps l .. k-2 and ALL the trees finish together: k launches, about 2 * nb additions in total, every launch a flat list of
+// independent additions (step s: 2^(k-s-1) halvings + (s+1) 2^(k-s-2) tree additions).  It replaces the chunked
+// running-sum reduction (55 dependent additions per lane over 65536 lanes = 3.6 M additions and 17 launches).
+// Storage per bucket set (points): A_1 .. A_k packed in nb slots (A_l at 2^k - 2^(k-l+1)); the trees ping-pong in another nb
+// slots (tree l at 2^k - 2^(k-l), two halves of 2^(k-l-2)).
+__host__ __device__ __forceinline__ uint32_t red_off_a(uint32_t k, uint32_t l) { return (1u << k) - (1u << (k - l + 1)); }   // l >= 1
+__host__ __device__ __forceinline__ uint32_t red_off_g(uint32_t k, uint32_t l) { return (1u << k) - (1u << (k - l)); }
+__host__ __device__ __forceinline__ uint32_t red_items(uint32_t k, uint32_t s) {   // additions of step s in one bucket set
+  const uint32_t nh = 1u << (k - s - 1);
+  return k >= s + 2 ? nh + (s + 1) * (1u << (k - s - 2)) : nh;
+}
 template <class C>
-__global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_reduce(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
-                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ tmp, uint32_t nb,
-                                                         uint32_t L, uint32_t n_chunks_total, int kbits) {
+__global__ void __launch_bounds__(256, vm_waves<C>()) k_reduce_step(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
+                                                       uint32_t* __restrict__ A, uint32_t* __restrict__ G, uint32_t n_sets, uint32_t k, uint32_t s) {
   const uint32_t t = logical_lane<typename C::F>();
-  if (t >= n_chunks_total) return;
+  const uint32_t per_set = red_items(k, s);
+  if (t >= n_sets * per_set) return;
   constexpr int PW = proj_words<C>();
-  const uint32_t chunks_per_window = nb / L;
-  const uint32_t w = t / chunks_per_window, ch = t % chunks_per_window;
-  const uint32_t k0 = ch * L;
-  const uint32_t base = w * nb + k0;
-  uint32_t* s_run = tmp + (size_t)t * 2 * PW;
-  uint32_t* s_R = s_run + PW;
-  uint32_t* s_acc = out + (size_t)t * PW;
-  {
+  const uint32_t set = t / per_set, r0 = t - set * per_set;
+  const uint32_t nb = 1u << k, nh = 1u << (k - s - 1);
+  const uint32_t* a_src = s == 0 ? buckets + (size_t)set * nb * PW : A + ((size_t)set * nb + red_off_a(k, s)) * PW;
+  uint32_t i0, i1;
+  const uint32_t* src;
+  uint32_t* dst;
+  if (r0 < nh) {                                   // halving: A_{s+1}[j] = A_s[2j] + A_s[2j+1]
+    i0 = 2u * r0; i1 = i0 + 1u; src = a_src;
+    dst = A + ((size_t)set * nb + red_off_a(k, s + 1) + r0) * PW;
+  } else {
+    const uint32_t sh = k - s - 2, r = r0 - nh, l = r >> sh, j = r & ((1u << sh) - 1u);
+    uint32_t* g = G + ((size_t)set * nb + red_off_g(k, l)) * PW;
+    const uint32_t half = 1u << (k - l - 2);
+    if (l == s) {                                  // first step of tree s: odd elements of A_s
+      i0 = 4u * j + 1u; i1 = i0 + 2u; src = a_src;
+      dst = g + (size_t)j * PW;
+    } else {                                       // tree l < s: one more level, ping-pong
+      i0 = 2u * j; i1 = i0 + 1u; src = g + (size_t)(((s - l - 1u) & 1u) * half) * PW;
+      dst = g + (size_t)(((s - l) & 1u) * half + j) * PW;
+    }
+  }
+  Proj<C> acc, Q;
+  // buckets no entry was sorted into hold stale data: they count as the identity (only A_0 = the bucket array has them)
+  const bool from_buckets = s == 0 && src == a_src;
+  const bool e0 = from_buckets && offsets[(size_t)set * nb + i0 + 1] == offsets[(size_t)set * nb + i0];
+  const bool e1 = from_buckets && offsets[(size_t)set * nb + i1 + 1] == offsets[(size_t)set * nb + i1];
+  if (e0) pt_set_zero(acc); else proj_load<C>(acc, src + (size_t)i0 * PW);
+  if (e1) pt_set_zero(Q); else proj_load<C>(Q, src + (size_t)i1 * PW);
+  const int pc = add_pc<C>(acc, Q);
+  pt_vm<C, true>(acc, Q, pc);
+  proj_store<C>(dst, acc);
+}
+// the k + 1 points the host combines, per bucket set: out[set][0] = T = A_k[0], out[set][1 + l] = G_l
+template <class C>
+__global__ void __launch_bounds__(64) k_reduce_collect(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
+                                                      const uint32_t* __restrict__ A, const uint32_t* __restrict__ G, uint32_t* __restrict__ out,
+                                                      uint32_t n_sets, uint32_t k) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_sets * (k + 1u)) return;
+  constexpr int PW = proj_words<C>();
+  const uint32_t set = t / (k + 1u), which = t - set * (k + 1u), nb = 1u << k;
+  const uint32_t* src;
+  bool empty = false;
+  if (which == 0) src = A + ((size_t)set * nb + red_off_a(k, k)) * PW;
+  else {
+    const uint32_t l = which - 1u;
+    if (l == k - 1u) {                              // G_{k-1} = A_{k-1}[1]; for k = 1 that is bucket 1 itself
+      if (k == 1u) { src = buckets + ((size_t)set * nb + 1u) * PW; empty = offsets[(size_t)set * nb + 2] == offsets[(size_t)set * nb + 1]; }
+      else src = A + ((size_t)set * nb + red_off_a(k, k - 1u) + 1u) * PW;
+    } else {
+      const uint32_t half = 1u << (k - l - 2);
+      src = G + ((size_t)set * nb + red_off_g(k, l) + ((k - 2u - l) & 1u) * half) * PW;
+    }
+  }
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)t * PW);
+  if (empty) {
+    // identity (0 : 1 : 0) in device form: written through the point type of the one-lane configuration
     Proj<C> z;
     pt_set_zero(z);
-    proj_store<C>(s_run, z);
-    proj_store<C>(s_R, z);
-    proj_store<C>(s_acc, z);
+    if constexpr (C::F::LANES == 1) proj_store<C>(out + (size_t)t * PW, z);
+    return;
   }
-  const int n_steps = 2 * (int)L + 2 * kbits + 1;
-  Proj<C> P, Q;
-  pt_set_zero(P);
-  pt_set_zero(Q);
-#pragma nounroll
-  for (int step = 0; step < n_steps; ++step) {
-    uint32_t* dst;
-    const uint32_t* src;
-    int mode;  // 0 = add, 1 = dbl, 2 = skip
-    if (step < 2 * (int)L) {
-      const uint32_t b = base + (L - 1u - (uint32_t)(step >> 1));
-      if ((step & 1) == 0) { dst = s_run; src = buckets + (size_t)b * PW; mode = (offsets[b + 1] != offsets[b]) ? 0 : 2; }
-      else { dst = s_acc; src = s_run; mode = 0; }
-    } else if (step < 2 * (int)L + 2 * kbits) {
-      const int q = step - 2 * (int)L;
-      const int bit = kbits - 1 - (q >> 1);
-      dst = s_R;
-      src = s_run;
-      if ((q & 1) == 0) mode = 1;
-      else mode = ((k0 >> bit) & 1u) ? 0 : 2;
-    } else {
-      dst = s_acc; src = s_R; mode = 0;
-    }
-    int pc = PC_END;
-    if (mode != 2) {
-      proj_load<C>(P, dst);
-      if (mode == 0) {
-        proj_load<C>(Q, src);
-        pc = add_pc<C>(P, Q);
-      } else {
-        pc = pt_is_zero(P) ? PC_END : PC_DBL;
-      }
-    }
-    pt_vm<C, true>(P, Q, pc);
-    if (mode != 2) proj_store<C>(dst, P);
-  }
-}
-
-// ---- per-window tree sum ----------------------------------------------------------------------------
-// in: [W][n_in] points, out: [W][n_out], n_out = ceil(n_in / R); lane sums R consecutive points
-template <class C>
-__global__ void __launch_bounds__(256, vm_waves<C>()) k_tree_sum(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t W,
-                                                    uint32_t n_in, uint32_t n_out, uint32_t R) {
-  const uint32_t t = logical_lane<typename C::F>();
-  if (t >= W * n_out) return;
-  const uint32_t w = t / n_out, o = t % n_out;
-  const uint32_t first = o * R;
-  uint32_t last = first + R;
-  if (last > n_in) last = n_in;
-  Proj<C> acc, Q;
-  proj_load<C>(acc, in + ((size_t)w * n_in + first) * proj_words<C>());
-  for (uint32_t k = first + 1; k < last; ++k) {
-    proj_load<C>(Q, in + ((size_t)w * n_in + k) * proj_words<C>());
-    int pc = add_pc<C>(acc, Q);
-    pt_vm<C, true>(acc, Q, pc);
-  }
-  proj_store<C>(out + ((size_t)w * n_out + o) * proj_words<C>(), acc);
+  const uint4* q = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+  for (int i = 0; i < PW / 4; ++i) dst[i] = q[i];
 }
 
 // ---- device form -> wire form (projective; identity is written as (0, 1, 0)) ----------------------------

@@ -6,14 +6,17 @@ cd "$(dirname "$0")/.."
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 python bench.py > $O/bench_line.json 2> $O/bench_stderr.log
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prove > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras > /dev/null 2>&1
 CURVE=0 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2 -o g2 -- python3 $R/tools/dev_msm_big.py 20 3 > $O/g2_msm_2p20.log 2>/dev/null
 CURVE=1 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2m6 -o g2 -- python3 $R/tools/dev_msm_big.py 15 3 > $O/g2_mnt6_msm_2p15.log 2>/dev/null
 cd $R
-sh tools/full_prove.sh MNT4753 20 skip-cpu > $O/full_prove_MNT4753_2p20.log 2>&1
-sh tools/full_prove.sh MNT6753 15 skip-cpu > $O/full_prove_MNT6753_2p15.log 2>&1
+sh tools/full_prove.sh MNT4753 20 > $O/full_prove_MNT4753_2p20.log 2>&1
+sh tools/full_prove.sh MNT6753 15 > $O/full_prove_MNT6753_2p15.log 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/kt_prove -o prove -- $R/snark-challenge-prover-reference_amd/main_hip MNT4753 compute /tmp/prove_keep/params /tmp/prove_keep/input /tmp/prove_keep/out --repeat 2 > $O/prove_under_rocprof.log 2>&1
+cd $R; rm -rf /tmp/prove_keep
 # keep the summaries, drop the bulky databases
 python3 - <<'PY'
 import sqlite3, glob, os, csv, collections
@@ -54,7 +57,7 @@ def per_msm(f, ctr):
     for r in csv.DictReader(open(f)):
         n = r["kernel"]
         if r["counter"] != ctr: continue
-        if "k_pair_add<mnt753::Mnt4G1>" in n or "k_bucket_accumulate<mnt753::Mnt4G1>" in n or "k_pair_fix" in n or "k_pair_counts" in n:
+        if "k_pair_level<mnt753::Mnt4G1" in n or "k_bucket_accumulate<mnt753::Mnt4G1>" in n or "k_pair_fix" in n:
             launches[n.split("(")[0]] = (int(r["launches"]), float(r["avg_value"]))
     acc = [v for k, v in launches.items() if "k_bucket_accumulate" in k]
     msms = acc[0][0] if acc else 1
@@ -62,7 +65,12 @@ def per_msm(f, ctr):
     return tot, launches, msms
 try:
     f, lf, m = per_msm(O + "/pmc_fetch_pmc.csv", "FETCH_SIZE"); w, lw, _ = per_msm(O + "/pmc_write_pmc.csv", "WRITE_SIZE")
-    json.dump({"phase": "bucket accumulation of one 2^20 G1 MSM: k_pair_add x levels + k_bucket_accumulate (+ k_pair_counts, k_pair_fix)",
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("msm_kernels.hip.h", "msm_host.hpp", "curve753.hip.h", "fp753.hip.h"):
+        h.update(open(os.path.join(os.getcwd(), "snark-challenge-prover-reference_amd", "csrc", name), "rb").read())
+    json.dump({"phase": "bucket accumulation of one 2^20 G1 MSM: k_pair_level x levels + k_bucket_accumulate (+ k_pair_fix)",
+               "kernels_fingerprint": h.hexdigest()[:16],
                "msms_averaged": m, "FETCH_SIZE_KB_per_msm": f, "WRITE_SIZE_KB_per_msm": w,
                "raw_bytes_per_msm": (f + w) * 1024, "hbm_bytes_per_launch": (2 * f + w) * 1024,
                "per_kernel_FETCH_KB": {k: {"launches": c, "avg": a} for k, (c, a) in lf.items()},
