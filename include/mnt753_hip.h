@@ -138,7 +138,9 @@ int mnt753_domain_create(int curve, size_t m, mnt753_domain** out);
 int mnt753_domain_free(mnt753_domain* d);
 size_t mnt753_domain_size(const mnt753_domain* d);   /* B::domain_get_m (hpp:47) */
 /* replaces B::domain_iFFT / domain_cosetFFT / domain_icosetFFT (hpp:42-45) and libfqfft FFT; in place on
- * a device vector of m Fr elements in wire format */
+ * a device vector of m Fr elements in wire format.  The transforms of one domain share its work buffer: calls on different
+ * streams are ordered on the device one after the other (an event per domain); host threads must not enter the same domain
+ * at the same time. */
 int mnt753_fft(mnt753_domain* d, int kind, uint64_t* dev_vec, void* stream);
 /* replaces B::domain_divide_by_Z_on_coset (hpp:46) */
 int mnt753_divide_by_z_on_coset(mnt753_domain* d, uint64_t* dev_vec, void* stream);

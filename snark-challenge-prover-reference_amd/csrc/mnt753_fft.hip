@@ -22,6 +22,7 @@ struct mnt753_domain {
   uint32_t *cos_inv_s = nullptr;                       // g^-i / m                    (m)
   uint32_t *consts = nullptr;                          // [0] 1/m  [1] 2^12 (k1)  [2] Z^-1 * 2^-12 (k2)  [3] Z^-1
   uint32_t *work = nullptr;                            // m wire elements
+  hipEvent_t work_free = nullptr;                      // recorded after every transform: the next user of `work` (any stream) waits for it
   uint32_t *stage = nullptr;                           // the seeds the tables were generated from (freed with the domain:
                                                        // hipFree is a device-wide sync and would wait for MSMs in flight)
 };
@@ -174,17 +175,34 @@ int mnt753_domain_free(mnt753_domain* d) {
   if (!d) return 0;
   void* ptrs[] = {d->tw_fwd, d->tw_inv, d->cos_fwd, d->cos_fwd_s, d->cos_inv_s, d->consts, d->work, d->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (d->work_free) (void)hipEventDestroy(d->work_free);
   delete d;
   return 0;
 }
 
 size_t mnt753_domain_size(const mnt753_domain* d) { return d ? d->m : 0; }
 
+// Every transform of a domain ping-pongs through the domain's one work buffer.  Callers on different streams are serialised on
+// the device: a transform first waits for the event the previous one recorded (host threads must still not call into the
+// same domain concurrently -- the threading contract of the reference wrapper).
+static int work_acquire(mnt753_domain* d, hipStream_t st) {
+  if (!d->work_free) HIP_TRY(hipEventCreateWithFlags(&d->work_free, hipEventDisableTiming));
+  else HIP_TRY(hipStreamWaitEvent(st, d->work_free, 0));
+  return 0;
+}
+static int work_release(mnt753_domain* d, hipStream_t st, int rc) {
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(d->work_free, st));
+  return 0;
+}
+
 int mnt753_fft(mnt753_domain* d, int kind, uint64_t* dev_vec, void* stream) {
   if (!d || !dev_vec) return set_error(MNT753_EINVAL, "fft: null argument");
   if (int rc = require_device()) return rc;
   uint32_t* v = reinterpret_cast<uint32_t*>(dev_vec);
-  return d->frm == MOD_A ? fft_t<MOD_A>(d, kind, v, (hipStream_t)stream) : fft_t<MOD_B>(d, kind, v, (hipStream_t)stream);
+  if (int rc = work_acquire(d, (hipStream_t)stream)) return rc;
+  const int rc = d->frm == MOD_A ? fft_t<MOD_A>(d, kind, v, (hipStream_t)stream) : fft_t<MOD_B>(d, kind, v, (hipStream_t)stream);
+  return work_release(d, (hipStream_t)stream, rc);
 }
 
 int mnt753_divide_by_z_on_coset(mnt753_domain* d, uint64_t* dev_vec, void* stream) {
@@ -229,7 +247,9 @@ int mnt753_compute_h(mnt753_domain* d, uint64_t* dev_ca, uint64_t* dev_cb, uint6
   if (int rc = require_device()) return rc;
   uint32_t *a = reinterpret_cast<uint32_t*>(dev_ca), *b = reinterpret_cast<uint32_t*>(dev_cb), *c = reinterpret_cast<uint32_t*>(dev_cc),
            *h = reinterpret_cast<uint32_t*>(dev_h);
-  return d->frm == MOD_A ? compute_h_t<MOD_A>(d, a, b, c, h, (hipStream_t)stream) : compute_h_t<MOD_B>(d, a, b, c, h, (hipStream_t)stream);
+  if (int rc = work_acquire(d, (hipStream_t)stream)) return rc;
+  const int rc = d->frm == MOD_A ? compute_h_t<MOD_A>(d, a, b, c, h, (hipStream_t)stream) : compute_h_t<MOD_B>(d, a, b, c, h, (hipStream_t)stream);
+  return work_release(d, (hipStream_t)stream, rc);
 }
 
 }  // extern "C"

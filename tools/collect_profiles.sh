@@ -12,11 +12,21 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python3 $R/bench.py --ste
 CURVE=0 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2 -o g2 -- python3 $R/tools/dev_msm_big.py 20 3 > $O/g2_msm_2p20.log 2>/dev/null
 CURVE=1 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2m6 -o g2 -- python3 $R/tools/dev_msm_big.py 15 3 > $O/g2_mnt6_msm_2p15.log 2>/dev/null
 cd $R
-sh tools/full_prove.sh MNT4753 20 > $O/full_prove_MNT4753_2p20.log 2>&1
-sh tools/full_prove.sh MNT6753 15 > $O/full_prove_MNT6753_2p15.log 2>&1
+export TMPDIR=/tmp
+K=/tmp/prove_keep; mkdir -p $K
+python3 tools/synth_files.py MNT4753 20 $K/p4 $K/i4 > /dev/null
+python3 tools/synth_files.py MNT6753 15 $K/p6 $K/i6 > /dev/null
+M=$R/snark-challenge-prover-reference_amd/main_hip
+{ echo "== main_hip MNT4753 d = 2^20 - 1, three proofs against resident parameters"; $M MNT4753 compute $K/p4 $K/i4 $K/o4 --repeat 3; sha256sum $K/o4;
+  echo "== the reference's call order and its unfused compute_H (--ref-order --unfused-h)"; $M MNT4753 compute $K/p4 $K/i4 $K/o4r --ref-order --unfused-h | grep -i "total\|load"; sha256sum $K/o4r;
+  echo "== two logical devices sharing the one GPU of this box (MNT753_SHARE_DEVICE=1 --gpus 2)"; MNT753_SHARE_DEVICE=1 $M MNT4753 compute $K/p4 $K/i4 $K/o4s --gpus 2 --repeat 2 | grep -i "total\|load"; sha256sum $K/o4s;
+  grep -A3 MNT4753_2p20 tests/golden/oracle_hashes.json | head -3; grep output_sha256 tests/golden/oracle_hashes.json; } > $O/full_prove_MNT4753_2p20.log 2>&1
+{ echo "== main_hip MNT6753 d = 2^15 - 1"; $M MNT6753 compute $K/p6 $K/i6 $K/o6 --repeat 3; sha256sum $K/o6;
+  echo "== CPU: the reference prover (oracle/_ref/main, $(nproc) hardware threads)"; [ -x oracle/_ref/main ] && ( /usr/bin/time -v oracle/_ref/main MNT6753 compute $K/p6 $K/i6 $K/o6ref 2>&1 | grep -i "total time\|elapsed\|Maximum resident" ; sha256sum $K/o6ref );
+  echo "== CPU: the oracle restatement (oracle_main)"; oracle/oracle_main MNT6753 compute $K/p6 $K/i6 $K/o6or; sha256sum $K/o6or; } > $O/full_prove_MNT6753_2p15.log 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/kt_prove -o prove -- $R/snark-challenge-prover-reference_amd/main_hip MNT4753 compute /tmp/prove_keep/params /tmp/prove_keep/input /tmp/prove_keep/out --repeat 2 > $O/prove_under_rocprof.log 2>&1
-cd $R; rm -rf /tmp/prove_keep
+rocprofv3 --kernel-trace --stats -d $O/kt_prove -o prove -- $M MNT4753 compute $K/p4 $K/i4 $K/o4 --repeat 2 > $O/prove_under_rocprof.log 2>&1
+cd $R; rm -rf $K
 # keep the summaries, drop the bulky databases
 python3 - <<'PY'
 import sqlite3, glob, os, csv, collections
