@@ -153,6 +153,22 @@ int mnt753_vec_subeq(int curve, uint64_t* dev_a, const uint64_t* dev_b, size_t n
 int mnt753_compute_h(mnt753_domain* d, uint64_t* dev_ca, uint64_t* dev_cb, uint64_t* dev_cc, uint64_t* dev_h,
                      void* stream);
 
+/* ---- witness-map front end (the step before the hot path) -------------------------------------------
+ * The reference evaluates the constraint system on the assignment on the CPU before the prover starts
+ * (libsnark/generate_parameters.cpp:44-57 writes the result into the input file as ca / cb / cc; it is the first loop of
+ * r1cs_to_qap_witness_map, libsnark/reductions/r1cs_to_qap/r1cs_to_qap.tcc:223-237).  Here the constraint system lives on the
+ * device as three CSR matrices (a, b, c) over the variables (1, w_1 .. w_m) -- column 0 is the constant one, i.e. w[0] of the
+ * input file -- and the evaluation is one kernel:
+ *   ca[i] = <a_i, w>, cb[i] = <b_i, w>, cc[i] = <c_i, w> for i < nc;  ca[nc + i] = w[i] for i <= num_inputs;  zero above.
+ * row_ptr[k]: nc + 1 offsets (row_ptr[k][0] = 0), col[k]: variable indices 0 .. m, coeff[k]: Fr elements in wire form;
+ * host pointers.  out_len = the evaluation domain size (d + 1 >= nc + num_inputs + 1). */
+typedef struct mnt753_r1cs mnt753_r1cs;
+int mnt753_r1cs_create(int curve, uint64_t num_inputs, uint64_t m, uint64_t nc, const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                       const uint64_t* const coeff[3], mnt753_r1cs** out);
+int mnt753_r1cs_free(mnt753_r1cs* r);
+size_t mnt753_r1cs_domain_size(const mnt753_r1cs* r);   /* nc + num_inputs + 1 */
+int mnt753_r1cs_evaluate(mnt753_r1cs* r, const uint64_t* dev_w, uint64_t* dev_ca, uint64_t* dev_cb, uint64_t* dev_cc, size_t out_len, void* stream);
+
 /* ---- deterministic synthetic inputs (host) ---------------------------------------------------------
  * Stand-in for libsnark/generate_parameters.cpp on machines that have neither the reference nor its
  * parameter files: bases with known discrete logarithms base[k] = e_k * G, uniform scalars, and the exact

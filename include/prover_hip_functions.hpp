@@ -40,6 +40,7 @@ public:
   struct vector_Fr;
   struct vector_G1;
   struct vector_G2;
+  class r1cs;   // extension: a constraint system resident on the device (witness-map front end)
 
   static void init_public_params();
 
@@ -103,6 +104,15 @@ public:
   // as libff cuts an MSM over OpenMP threads (multiexp.tcc:417-431); multiexp_G1 / multiexp_G2 run the slices concurrently
   // and fold the partial results in rank order (multiexp.tcc:433-438).  The FFTs stay on device 0.
   static void use_devices(int n);
+  // The step before the hot path: instead of reading ca / cb / cc from the input file (where the
+  // reference's generator put them, generate_parameters.cpp:44-57), evaluate the constraint system on the assignment on the
+  // device -- the first loop of r1cs_to_qap_witness_map (reductions/r1cs_to_qap/r1cs_to_qap.tcc:223-237).
+  // read_r1cs: the file written by oracle/ref_groth16.cpp (u64 num_inputs, m, nc; per matrix a, b, c: u64 row_ptr[nc + 1],
+  // u32 col[nnz], Fr coeff[nnz]).  read_witness: a file holding w[m + 1] and r only; the returned groth16_input behaves like
+  // one from read_input.
+  static r1cs *read_r1cs(const char *path);
+  static groth16_input *read_witness(const char *path, groth16_params *params, r1cs *cs);
+  static void delete_r1cs(r1cs *a);
   // seconds the background loader of read_input needed until the whole input file was on the device (waits for it)
   static double input_load_seconds(groth16_input *input);
   // raw access for tests / tools

@@ -16,7 +16,8 @@ GMP_SO=/usr/lib/x86_64-linux-gnu/libgmp.so.10
 [ -d "$R/libsnark" ] || { echo "build_ref: $R not found"; exit 0; }
 [ -f /opt/conda/include/gmp.h ] && [ -f $GMP_SO ] || { echo "build_ref: GMP header/library missing -- reference unbuildable here"; exit 0; }
 if [ -x $O/main ] && [ -x $O/generate_parameters ] && [ -x $O/piecewise_host ] && [ -x $O/mint_golden ] && [ $O/mint_golden -nt $HERE/mint_golden.cpp ] \
-   && [ -x $O/ref_msm_bench ] && [ $O/ref_msm_bench -nt $HERE/ref_msm_bench.cpp ]; then
+   && [ -x $O/ref_msm_bench ] && [ $O/ref_msm_bench -nt $HERE/ref_msm_bench.cpp ] \
+   && [ -x $O/ref_groth16 ] && [ $O/ref_groth16 -nt $HERE/ref_groth16.cpp ]; then
   echo "build_ref: oracle/_ref up to date"; exit 0
 fi
 mkdir -p $O/inc $O/obj
@@ -43,5 +44,7 @@ g++ $F -I$R/libsnark/prover_reference_include $O/piecewise_host.gen.cpp $O/prf.o
 g++ $F -I$R/libsnark/prover_reference_include $HERE/mint_golden.cpp $O/obj/*.o -o $O/mint_golden $GMP_SO & PIDS="$PIDS $!"
 # CPU-baseline driver for bench.py: OUR program around the reference's multi_exp (BDLO12), as B::multiexp_G1 calls it
 g++ $F $HERE/ref_msm_bench.cpp $O/obj/*.o -o $O/ref_msm_bench $GMP_SO & PIDS="$PIDS $!"
+# fixtures + checker for the steps either side of the hot path (witness map, full proof + verifier): OUR program on the reference's libsnark
+g++ $F $HERE/ref_groth16.cpp $O/obj/*.o -o $O/ref_groth16 $GMP_SO & PIDS="$PIDS $!"
 wait_all
 echo "build_ref: built $(ls $O | tr '\n' ' ')"

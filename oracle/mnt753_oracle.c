@@ -684,6 +684,52 @@ int oracle_msm(int curve, int group, const uint64_t* bases, const uint64_t* scal
   free(pts); free(ex);
   return 0;
 }
+/* Evaluation of the constraint system on the assignment: the first loop of r1cs_to_qap_witness_map
+ * (S/reductions/r1cs_to_qap/r1cs_to_qap.tcc:223-237) = S/generate_parameters.cpp:44-57.  Matrices in CSR over the variables
+ * (1, w_1 .. w_m) -- column 0 is the constant one = w[0] of the input file; linear_combination::evaluate, relations/variable.tcc.
+ * ca, cb, cc: out_len elements each. */
+int oracle_r1cs_evaluate(int curve, uint64_t num_inputs, uint64_t nc, const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                         const uint64_t* const coeff[3], const uint64_t* w, uint64_t* ca, uint64_t* cb, uint64_t* cc, size_t out_len) {
+  if (curve < 0 || curve > 1 || out_len < nc + num_inputs + 1) return -1;
+  const int mod = curve == 0 ? 0 : 1;
+  uint64_t* outv[3] = {ca, cb, cc};
+  for (int k = 0; k < 3; ++k) {
+    memset(outv[k], 0, 96 * out_len);
+    for (uint64_t i = 0; i < nc; ++i) {
+      fp_t acc; memset(&acc, 0, sizeof(acc));
+      for (uint64_t t = row_ptr[k][i]; t < row_ptr[k][i + 1]; ++t) {
+        fp_t c, x, p;
+        memcpy(c.l, coeff[k] + 12 * t, 96); memcpy(x.l, w + 12 * (size_t)col[k][t], 96);
+        fp_mul(&p, &c, &x, mod);
+        fp_add(&acc, &acc, &p, mod);
+      }
+      memcpy(outv[k] + 12 * i, acc.l, 96);
+    }
+  }
+  for (uint64_t i = 0; i <= num_inputs; ++i) memcpy(ca + 12 * (nc + i), w + 12 * i, 96);   /* input consistency rows (:223-227) */
+  return 0;
+}
+/* Completion of a challenge proof to a full Groth16 proof, S/main.cpp:312-319:
+ *   A' = alpha + A + r delta,  B' = beta + B + s delta,  C' = C + s A' + r beta.
+ * keys = alpha_g1 | beta_g1 | beta_g2 | delta_g1 | delta_g2, proof / out = A | B | C, all affine wire; r, s Fr wire. */
+int oracle_complete_proof(int curve, const uint64_t* keys, const uint64_t* proof, const uint64_t* r, const uint64_t* s, uint64_t* out) {
+  if (curve < 0 || curve > 1) return -1;
+  group_t g1, g2; group_init(&g1, curve, 1); group_init(&g2, curve, 2);
+  const int w1 = group_affine_words(&g1), w2 = group_affine_words(&g2);
+  const uint64_t *alpha1 = keys, *beta1 = keys + w1, *beta2 = beta1 + w1, *delta1 = beta2 + w2, *delta2 = delta1 + w1;
+  fp_t fr, fs; memcpy(fr.l, r, 96); memcpy(fs.l, s, 96);
+  uint64_t er[NLIMB], es[NLIMB];
+  fp_as_bigint(er, &fr, g1.fr_mod); fp_as_bigint(es, &fs, g1.fr_mod);
+  pt_t A, B, C, t, u;
+  pt_from_wire(&A, proof, &g1); pt_from_wire(&t, alpha1, &g1); pt_add(&A, &t, &A, &g1);
+  pt_from_wire(&t, delta1, &g1); pt_scalar_mul(&u, &t, er, &g1); pt_add(&A, &A, &u, &g1);
+  pt_from_wire(&B, proof + w1, &g2); pt_from_wire(&t, beta2, &g2); pt_add(&B, &t, &B, &g2);
+  pt_from_wire(&t, delta2, &g2); pt_scalar_mul(&u, &t, es, &g2); pt_add(&B, &B, &u, &g2);
+  pt_from_wire(&C, proof + w1 + w2, &g1); pt_scalar_mul(&u, &A, es, &g1); pt_add(&C, &C, &u, &g1);
+  pt_from_wire(&t, beta1, &g1); pt_scalar_mul(&u, &t, er, &g1); pt_add(&C, &C, &u, &g1);
+  pt_to_wire(out, &A, &g1); pt_to_wire(out + w1, &B, &g2); pt_to_wire(out + w1 + w2, &C, &g1);
+  return 0;
+}
 int oracle_fft(int curve, int kind, uint64_t* vec, size_t m) {
   if (curve < 0 || curve > 1 || kind < 0 || kind > 3) return -1;
   return fr_domain_fft((fp_t*)vec, m, kind, curve == 0 ? 0 : 1);

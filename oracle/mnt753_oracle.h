@@ -15,6 +15,9 @@ int oracle_fft(int curve, int kind, uint64_t* vec, size_t m);   /* kind 0 FFT, 1
 int oracle_divide_by_z_on_coset(int curve, uint64_t* vec, size_t m);
 int oracle_compute_h(int curve, uint64_t* ca, uint64_t* cb, uint64_t* cc, uint64_t* h, size_t m);
 int oracle_prove(int curve, const char* params_path, const char* input_path, const char* output_path, size_t chunks, double* timings4);
+int oracle_r1cs_evaluate(int curve, uint64_t num_inputs, uint64_t nc, const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                         const uint64_t* const coeff[3], const uint64_t* w, uint64_t* ca, uint64_t* cb, uint64_t* cc, size_t out_len);
+int oracle_complete_proof(int curve, const uint64_t* keys, const uint64_t* proof, const uint64_t* r, const uint64_t* s, uint64_t* out);
 int oracle_max_threads(void);
 #ifdef __cplusplus
 }

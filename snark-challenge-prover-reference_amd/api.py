@@ -74,6 +74,10 @@ def lib():
         "mnt753_synth_scalars": (i, [i, C.c_uint64, sz, u64p]),
         "mnt753_synth_expected_msm": (i, [i, i, C.c_uint64, sz, u64p, u64p]),
         "mnt753_test_field_op": (i, [i, i, u64p, u64p, sz, u64p]),
+        "mnt753_r1cs_create": (i, [i, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "mnt753_r1cs_free": (i, [vp]),
+        "mnt753_r1cs_domain_size": (sz, [vp]),
+        "mnt753_r1cs_evaluate": (i, [vp, vp, vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = the library does not export what the header declares
@@ -299,6 +303,55 @@ def synth_expected_msm(curve, group, seed, scalars):
     out = np.zeros(projective_words(curve, group), dtype=np.uint64)
     _check(lib().mnt753_synth_expected_msm(curve, group, seed, s.size // 12, ps, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_synth_expected_msm")
     return out
+
+
+def read_r1cs_file(path):
+    """r1cs.bin of oracle/ref_groth16.cpp: u64 num_inputs, m, nc; per matrix a, b, c: u64 row_ptr[nc + 1], u32 col[nnz], Fr coeff[nnz]."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    num_inputs, m, nc = (int(v) for v in raw[:24].view(np.uint64))
+    pos, mats = 24, []
+    for _ in range(3):
+        rp = raw[pos:pos + 8 * (nc + 1)].view(np.uint64).copy(); pos += 8 * (nc + 1)
+        nnz = int(rp[nc])
+        col = raw[pos:pos + 4 * nnz].view(np.uint32).copy(); pos += 4 * nnz
+        cf = raw[pos:pos + 96 * nnz].view(np.uint64).copy().reshape(nnz, 12); pos += 96 * nnz
+        mats.append((rp, col, cf))
+    assert pos == raw.size
+    return num_inputs, m, nc, mats
+
+
+class R1cs:
+    """Device-resident constraint system (mnt753_r1cs_*): the witness-map front end."""
+
+    def __init__(self, curve, num_inputs, m, nc, mats):
+        self.curve, self.num_inputs, self.m, self.nc = curve, num_inputs, m, nc
+        self._h = C.c_void_p()
+        self._keep = [(np.ascontiguousarray(rp, dtype=np.uint64), np.ascontiguousarray(col, dtype=np.uint32), np.ascontiguousarray(cf, dtype=np.uint64)) for rp, col, cf in mats]
+        arr = lambda k: (C.c_void_p * 3)(*[C.c_void_p(t[k].ctypes.data) for t in self._keep])
+        _check(lib().mnt753_r1cs_create(curve, num_inputs, m, nc, arr(0), arr(1), arr(2), C.byref(self._h)), "mnt753_r1cs_create")
+
+    @classmethod
+    def from_file(cls, curve, path):
+        return cls(curve, *read_r1cs_file(path))
+
+    def domain_size(self):
+        return int(lib().mnt753_r1cs_domain_size(self._h))
+
+    def evaluate(self, dev_w, dev_ca, dev_cb, dev_cc, out_len, stream=None):
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+        _check(lib().mnt753_r1cs_evaluate(self._h, C.c_void_p(int(dev_w)), C.c_void_p(int(dev_ca)), C.c_void_p(int(dev_cb)), C.c_void_p(int(dev_cc)),
+                                          int(out_len), st), "mnt753_r1cs_evaluate")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mnt753_r1cs_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def test_field_op(mod, op, a, b=None):

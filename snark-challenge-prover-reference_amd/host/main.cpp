@@ -1,4 +1,6 @@
-// ./main_hip <curve> compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--unfused-h] [--ref-order] [--quiet]
+// ./main_hip <curve> compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--unfused-h] [--ref-order] [--quiet]
+// ./main_hip <curve> compute-r1cs <params> <r1cs> <witness> <output> ...      (ca / cb / cc evaluated on the device from the constraint system)
+// ./main_hip <curve> complete <keys> <input|witness> <challenge_proof> <full_proof> [--s-file <Fr> | --s-seed N]
 //
 // The prover driver, same command line as the reference binaries (libsnark/main.cpp:274-293,
 // cuda_prover_piecewise.cu:100-120).  compute_H<B> and run_prover<B> keep the reference's shape -- they are
@@ -14,6 +16,7 @@
 #include <utility>
 #include <vector>
 
+#include "../../include/mnt753_hip.h"
 #include "../../include/prover_hip_functions.hpp"
 
 // Defaults = the fastest schedule on one MI355X: the G2 MSM is enqueued as soon as w is on the device, compute_H (one fused
@@ -61,10 +64,12 @@ typename B::vector_Fr* compute_H(size_t d, typename B::vector_Fr* ca, typename B
 // the parameters are loaded once and stay resident (window tables, workspaces, evaluation domain); every (input, output)
 // pair after that is one proof.  With a single pair this is exactly the reference's run_prover.
 template <typename B>
-void prove_one(typename B::groth16_params* params, const char* input_path, const char* output_path, clk::time_point t0, bool first) {
+void prove_one(typename B::groth16_params* params, const char* input_path, const char* output_path, clk::time_point t0, bool first,
+               typename B::r1cs* cs = nullptr) {
   const size_t primary_input_size = 1;
   auto t_main = clk::now();
-  auto input = B::read_input(input_path, params);
+  // compute-r1cs: the input file holds w and r only; ca / cb / cc come from the constraint system, evaluated on the device
+  auto input = cs ? B::read_witness(input_path, params, cs) : B::read_input(input_path, params);
   auto t_in = clk::now();
   if (!g_quiet) printf("load inputs (started in the background): %.3fs\n", secs(t_main, t_in));
 
@@ -129,33 +134,104 @@ void prove_one(typename B::groth16_params* params, const char* input_path, const
 
 // jobs: (input, output) pairs; all proved against the same resident parameters
 template <typename B>
-void run_prover(const char* params_path, const std::vector<std::pair<std::string, std::string>>& jobs) {
+void run_prover(const char* params_path, const std::vector<std::pair<std::string, std::string>>& jobs, const char* r1cs_path = nullptr) {
   if (g_gpus > 0) B::use_devices(g_gpus);
   B::init_public_params();
   auto t0 = clk::now();
   auto params = B::read_params(params_path);
+  typename B::r1cs* cs = r1cs_path ? B::read_r1cs(r1cs_path) : nullptr;
   auto t_params = clk::now();
   if (!g_quiet) printf("load params: %.3fs\n", secs(t0, t_params));
   bool first = true;
   for (const auto& job : jobs) {
     if (!g_quiet && jobs.size() > 1) printf("-- proof %s -> %s\n", job.first.c_str(), job.second.c_str());
-    prove_one<B>(params, job.first.c_str(), job.second.c_str(), t0, first);
+    prove_one<B>(params, job.first.c_str(), job.second.c_str(), t0, first, cs);
     first = false;
   }
+  if (cs) B::delete_r1cs(cs);
   B::delete_groth16_params(params);
+}
+
+// ./main_hip <curve> complete <keys> <input|witness> <challenge_proof> <full_proof> [--s-file <Fr> | --s-seed N]
+//
+// The step AFTER the hot path: the challenge prover stops at (A, B, C) = (sum w_i A_i, sum w_i B_i,
+// Ht + Lt + r Bt1); libsnark/main.cpp:312-319 shows how the reference completes that to a Groth16 proof a verifier accepts:
+//     A' = alpha + A + r delta,    B' = beta + B + s delta,    C' = C + s A' + r beta          (r from the input file, s fresh)
+// keys = alpha_g1 | beta_g1 | beta_g2 | delta_g1 | delta_g2 in the wire format (oracle/ref_groth16.cpp mints them from the
+// reference's generator).  O(1) group operations on the host through the C ABI; no GPU needed.
+static void slurp(const char* path, long offset_from_end, void* dst, size_t bytes) {
+  FILE* f = fopen(path, "rb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+  if (offset_from_end && fseek(f, -offset_from_end, SEEK_END) != 0) { fclose(f); throw std::runtime_error(std::string("seek failed: ") + path); }
+  if (fread(dst, 1, bytes, f) != bytes) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
+  fclose(f);
+}
+static void ck(int rc, const char* what) { if (rc) throw std::runtime_error(std::string(what) + ": " + mnt753_last_error()); }
+static int complete_proof(int curve, const char* keys_path, const char* input_path, const char* challenge_path, const char* out_path,
+                          const char* s_file, uint64_t s_seed) {
+  const size_t g1 = 24, g2 = mnt753_affine_words(curve, MNT753_G2);
+  std::vector<uint64_t> keys(3 * g1 + 2 * g2), proof(2 * g1 + g2);
+  slurp(keys_path, 0, keys.data(), keys.size() * 8);
+  slurp(challenge_path, 0, proof.data(), proof.size() * 8);
+  uint64_t r[12], s[12];
+  slurp(input_path, 96, r, 96);
+  if (s_file) slurp(s_file, 0, s, 96); else ck(mnt753_synth_scalars(curve, s_seed, 1, s), "mnt753_synth_scalars");
+  const uint64_t *alpha1 = keys.data(), *beta1 = alpha1 + g1, *beta2 = beta1 + g1, *delta1 = beta2 + g2, *delta2 = delta1 + g1;
+  auto lift = [&](int group, const uint64_t* aff, uint64_t* proj) { ck(mnt753_point_from_affine(curve, group, aff, proj), "mnt753_point_from_affine"); };
+  uint64_t pa[36], pb[108], pc[36], t1[36], t2[108], u1[36], u2[108];
+  // A' = alpha + A + r delta
+  lift(MNT753_G1, proof.data(), pa); lift(MNT753_G1, alpha1, t1);
+  ck(mnt753_point_add(curve, MNT753_G1, t1, pa, pa), "mnt753_point_add");
+  lift(MNT753_G1, delta1, t1); ck(mnt753_point_scale(curve, MNT753_G1, r, t1, u1), "mnt753_point_scale");
+  ck(mnt753_point_add(curve, MNT753_G1, pa, u1, pa), "mnt753_point_add");
+  // B' = beta + B + s delta
+  lift(MNT753_G2, proof.data() + g1, pb); lift(MNT753_G2, beta2, t2);
+  ck(mnt753_point_add(curve, MNT753_G2, t2, pb, pb), "mnt753_point_add");
+  lift(MNT753_G2, delta2, t2); ck(mnt753_point_scale(curve, MNT753_G2, s, t2, u2), "mnt753_point_scale");
+  ck(mnt753_point_add(curve, MNT753_G2, pb, u2, pb), "mnt753_point_add");
+  // C' = C + s A' + r beta
+  lift(MNT753_G1, proof.data() + g1 + g2, pc);
+  ck(mnt753_point_scale(curve, MNT753_G1, s, pa, u1), "mnt753_point_scale");
+  ck(mnt753_point_add(curve, MNT753_G1, pc, u1, pc), "mnt753_point_add");
+  lift(MNT753_G1, beta1, t1); ck(mnt753_point_scale(curve, MNT753_G1, r, t1, u1), "mnt753_point_scale");
+  ck(mnt753_point_add(curve, MNT753_G1, pc, u1, pc), "mnt753_point_add");
+  std::vector<uint64_t> out(2 * g1 + g2);
+  ck(mnt753_point_to_affine(curve, MNT753_G1, pa, out.data()), "mnt753_point_to_affine");
+  ck(mnt753_point_to_affine(curve, MNT753_G2, pb, out.data() + g1), "mnt753_point_to_affine");
+  ck(mnt753_point_to_affine(curve, MNT753_G1, pc, out.data() + g1 + g2), "mnt753_point_to_affine");
+  FILE* f = fopen(out_path, "wb");
+  if (!f) throw std::runtime_error(std::string("cannot open output file ") + out_path);
+  fwrite(out.data(), 8, out.size(), f);
+  fclose(f);
+  return 0;
 }
 
 int main(int argc, char** argv) {
   setbuf(stdout, NULL);
+  if (argc >= 7 && !strcmp(argv[2], "complete")) {
+    const int curve = !strcmp(argv[1], "MNT4753") ? 0 : (!strcmp(argv[1], "MNT6753") ? 1 : -1);
+    if (curve < 0) { fprintf(stderr, "unknown curve %s\n", argv[1]); return 2; }
+    const char* s_file = nullptr; uint64_t s_seed = 0x73656564ull;
+    for (int i = 7; i + 1 < argc; i += 2) {
+      if (!strcmp(argv[i], "--s-file")) s_file = argv[i + 1];
+      else if (!strcmp(argv[i], "--s-seed")) s_seed = strtoull(argv[i + 1], nullptr, 0);
+    }
+    try { return complete_proof(curve, argv[3], argv[4], argv[5], argv[6], s_file, s_seed); }
+    catch (const std::exception& e) { fprintf(stderr, "main_hip: %s\n", e.what()); return 1; }
+  }
   if (argc < 6) {
     fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--unfused-h] [--ref-order] [--quiet]\n"
                     "  further (input, output) pairs and --repeat prove against the parameters that are already resident on the GPU\n", argv[0]);
     return 2;
   }
+  // compute-r1cs <params> <r1cs> <witness> <output>: one more positional argument than compute
+  const bool with_r1cs = !strcmp(argv[2], "compute-r1cs");
+  if (with_r1cs && argc < 7) { fprintf(stderr, "usage: %s <curve> compute-r1cs <params> <r1cs> <witness> <output>\n", argv[0]); return 2; }
+  const int a0 = with_r1cs ? 5 : 4;
   std::vector<std::pair<std::string, std::string>> jobs;
-  jobs.emplace_back(argv[4], argv[5]);
+  jobs.emplace_back(argv[a0], argv[a0 + 1]);
   int repeat = 1;
-  for (int i = 6; i < argc; ++i) {
+  for (int i = a0 + 2; i < argc; ++i) {
     if (!strcmp(argv[i], "--repeat") && i + 1 < argc) { repeat = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { g_gpus = atoi(argv[++i]); continue; }
     if (argv[i][0] != '-' && i + 1 < argc && argv[i + 1][0] != '-') { jobs.emplace_back(argv[i], argv[i + 1]); ++i; continue; }
@@ -167,10 +243,11 @@ int main(int argc, char** argv) {
   }
   std::string curve(argv[1]), mode(argv[2]);
   try {
-    if (mode != "compute") { fprintf(stderr, "unknown mode %s\n", argv[2]); return 2; }
+    if (mode != "compute" && mode != "compute-r1cs") { fprintf(stderr, "unknown mode %s\n", argv[2]); return 2; }
     if (repeat > 1) { const auto one = jobs; for (int k = 1; k < repeat; ++k) jobs.insert(jobs.end(), one.begin(), one.end()); }
-    if (curve == "MNT4753") run_prover<mnt4753_hip>(argv[3], jobs);
-    else if (curve == "MNT6753") run_prover<mnt6753_hip>(argv[3], jobs);
+    const char* r1cs_path = with_r1cs ? argv[4] : nullptr;
+    if (curve == "MNT4753") run_prover<mnt4753_hip>(argv[3], jobs, r1cs_path);
+    else if (curve == "MNT6753") run_prover<mnt6753_hip>(argv[3], jobs, r1cs_path);
     else { fprintf(stderr, "unknown curve %s\n", argv[1]); return 2; }
   } catch (const std::exception& e) {
     fprintf(stderr, "main_hip: %s\n", e.what());

@@ -154,6 +154,46 @@ public:
   }
 };
 
+struct R1csHolder {
+  mnt753_r1cs* h = nullptr;
+  ~R1csHolder() { if (h) mnt753_r1cs_free(h); }
+};
+template <int CURVE>
+class mnt753_hip_impl<CURVE>::r1cs {
+public:
+  std::shared_ptr<R1csHolder> data;
+  uint64_t num_inputs = 0, m = 0, nc = 0;
+  explicit r1cs(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open r1cs file ") + path);
+    uint64_t hdr[3];
+    read_exact(f, hdr, 24, path);
+    num_inputs = hdr[0]; m = hdr[1]; nc = hdr[2];
+    struct stat st;
+    if (stat(path, &st) != 0 || nc > ((uint64_t)1 << 31) || m > ((uint64_t)1 << 31) || (uint64_t)st.st_size < 24 + 3 * 8 * (nc + 1)) {
+      fclose(f);
+      throw std::runtime_error(std::string("bad r1cs header in ") + path);
+    }
+    std::vector<uint64_t> rp[3], cf[3];
+    std::vector<uint32_t> col[3];
+    for (int k = 0; k < 3; ++k) {
+      rp[k].resize(nc + 1);
+      read_exact(f, rp[k].data(), 8 * (nc + 1), path);
+      const uint64_t nnz = rp[k][nc];
+      if (nnz > (uint64_t)st.st_size / 100) { fclose(f); throw std::runtime_error(std::string("r1cs file shorter than its row pointers say: ") + path); }
+      col[k].resize(nnz); cf[k].resize(12 * nnz);
+      read_exact(f, col[k].data(), 4 * nnz, path);
+      read_exact(f, cf[k].data(), 96 * nnz, path);
+    }
+    fclose(f);
+    const uint64_t* rpp[3] = {rp[0].data(), rp[1].data(), rp[2].data()};
+    const uint32_t* cp[3] = {col[0].data(), col[1].data(), col[2].data()};
+    const uint64_t* fp[3] = {cf[0].data(), cf[1].data(), cf[2].data()};
+    data = std::make_shared<R1csHolder>();
+    check(mnt753_r1cs_create(CURVE, num_inputs, m, nc, rpp, cp, fp, &data->h), "mnt753_r1cs_create");
+  }
+};
+
 // input file: w[m+1], ca[d+1], cb[d+1], cc[d+1], r   (generate_parameters.cpp:88-108, reader :48-76)
 // The constructor returns at once; a loader thread streams the four vectors to the device in file order and releases
 // them one by one, so kernels that only need w (four of the five MSMs) start while ca / cb / cc are still being read.
@@ -201,6 +241,41 @@ public:
         if (k + 1 == parts.size()) *secs_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         part.ready->set(err);
       }
+    });
+  }
+  // witness file: w[m+1], r.  ca / cb / cc are evaluated on the device from the constraint system as soon as w is there.
+  groth16_input(const char* path, size_t d, size_t m, std::shared_ptr<R1csHolder> cs) {
+    n_w = m + 1; n_c = d + 1;
+    struct stat st;
+    if (stat(path, &st) != 0 || (unsigned long long)st.st_size != 96ull * (n_w + 1))
+      throw std::runtime_error(std::string("witness file size does not match the parameters (expected ") + std::to_string(96 * (n_w + 1)) + " bytes): " + path);
+    if (mnt753_r1cs_domain_size(cs->h) > n_c) throw std::runtime_error("the constraint system does not fit the parameters' evaluation domain");
+    FILE* f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open witness file ") + path);
+    if (fseeko(f, (off_t)(96 * n_w), SEEK_SET) != 0 || fread(r, 1, 96, f) != 96) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
+    fclose(f);
+    w = std::make_shared<DeviceBuffer>(96 * n_w);
+    ca = std::make_shared<DeviceBuffer>(96 * n_c);
+    cb = std::make_shared<DeviceBuffer>(96 * n_c);
+    cc = std::make_shared<DeviceBuffer>(96 * n_c);
+    w_ready = std::make_shared<Ready>(); ca_ready = std::make_shared<Ready>(); cb_ready = std::make_shared<Ready>();
+    cc_ready = std::make_shared<Ready>();
+    const std::string p(path);
+    auto secs_out = load_seconds;
+    auto w_ = w, ca_ = ca, cb_ = cb, cc_ = cc;
+    auto wr = w_ready, ar = ca_ready, br = cb_ready, cr = cc_ready;
+    const size_t nw = n_w, ncc = n_c;
+    loader = std::thread([p, secs_out, w_, ca_, cb_, cc_, wr, ar, br, cr, nw, ncc, cs]() {
+      const auto t0 = std::chrono::steady_clock::now();
+      std::string err;
+      if (mnt753_load_file_to_device(p.c_str(), 0, 96 * nw, w_->ptr) != 0) err = std::string("mnt753_load_file_to_device: ") + mnt753_last_error();
+      wr->set(err);
+      if (err.empty() && (mnt753_r1cs_evaluate(cs->h, reinterpret_cast<const uint64_t*>(w_->ptr), reinterpret_cast<uint64_t*>(ca_->ptr),
+                                               reinterpret_cast<uint64_t*>(cb_->ptr), reinterpret_cast<uint64_t*>(cc_->ptr), ncc, nullptr) != 0 ||
+                          mnt753_sync(nullptr) != 0))
+        err = std::string("mnt753_r1cs_evaluate: ") + mnt753_last_error();
+      *secs_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      ar->set(err); br->set(err); cr->set(err);
     });
   }
   ~groth16_input() { if (loader.joinable()) loader.join(); }
@@ -361,6 +436,11 @@ template <int CURVE> typename HIP_B::G2* HIP_B::multiexp_G2(vector_Fr* scalar_st
 template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_input(const char* path, groth16_params* params) {
   return new groth16_input(path, params->d, params->m);
 }
+template <int CURVE> typename HIP_B::r1cs* HIP_B::read_r1cs(const char* path) { return new r1cs(path); }
+template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_witness(const char* path, groth16_params* params, r1cs* cs) {
+  return new groth16_input(path, params->d, params->m, cs->data);
+}
+template <int CURVE> void HIP_B::delete_r1cs(r1cs* a) { delete a; }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_w(groth16_input* in) { return new vector_Fr{in->w, in->n_w, 0, in->w_ready}; }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_ca(groth16_input* in) { return new vector_Fr{in->ca, in->n_c, 0, in->ca_ready}; }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cb(groth16_input* in) { return new vector_Fr{in->cb, in->n_c, 0, in->cb_ready}; }

@@ -25,6 +25,8 @@ def lib():
         L.oracle_divide_by_z_on_coset.argtypes = [i, u64p, sz]
         L.oracle_compute_h.argtypes = [i, u64p, u64p, u64p, u64p, sz]
         L.oracle_prove.argtypes = [i, C.c_char_p, C.c_char_p, C.c_char_p, sz, C.POINTER(C.c_double)]
+        L.oracle_r1cs_evaluate.argtypes = [i, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p, u64p, u64p, u64p, sz]
+        L.oracle_complete_proof.argtypes = [i, u64p, u64p, u64p, u64p, u64p]
         L.oracle_max_threads.restype = i
         _LIB = L
     return _LIB
@@ -91,6 +93,24 @@ def compute_h(curve, ca, cb, cc):
     h = np.zeros((m + 1) * 12, dtype=np.uint64)
     assert lib().oracle_compute_h(curve, _p(ca), _p(cb), _p(cc), _p(h), m) == 0
     return h
+
+
+def r1cs_evaluate(curve, num_inputs, nc, mats, w, out_len):
+    """mats: [(row_ptr u64, col u32, coeff u64[nnz,12])] x 3; w: (m + 1, 12).  Returns ca, cb, cc of out_len rows."""
+    keep = [(_arr(rp), np.ascontiguousarray(col, dtype=np.uint32), _arr(cf)) for rp, col, cf in mats]
+    arr = lambda k: (C.c_void_p * 3)(*[C.c_void_p(t[k].ctypes.data) for t in keep])
+    w = _arr(w)
+    outs = [np.zeros((out_len, 12), dtype=np.uint64) for _ in range(3)]
+    rc = lib().oracle_r1cs_evaluate(curve, num_inputs, nc, arr(0), arr(1), arr(2), _p(w), _p(outs[0]), _p(outs[1]), _p(outs[2]), out_len)
+    assert rc == 0, rc
+    return outs
+
+
+def complete_proof(curve, keys, proof, r, s):
+    keys, proof, r, s = _arr(keys), _arr(proof), _arr(r), _arr(s)
+    out = np.zeros_like(proof)
+    assert lib().oracle_complete_proof(curve, _p(keys), _p(proof), _p(r), _p(s), _p(out)) == 0
+    return out
 
 
 def prove(curve, params, inp, out, chunks=None):
