@@ -271,10 +271,12 @@ def main():
         achieved = ALGO_BYTES_PER_PAIR * n / (acc * 1e-3) / 1e9
         plan_c, windows = plan["window_bits"], plan["windows"]
         levels = plan.get("pair_levels", 0)
-        # Montgomery products per sorted entry: 6 per affine pair addition (3 + 3 for the simultaneous inversion) on 1/2, 1/4, ...
-        # of the entries, ~94 / batch for the divstep inversion, 11 per mixed addition on what is left
-        prod_per_entry = sum((6.0 + 94.0 / (155.0 if l == 1 else 96.0)) / 2 ** l for l in range(1, levels + 1)) + 11.0 / 2 ** levels
-        kernel_name = "k_bucket_accumulate<Mnt4G1>" if levels == 0 else f"k_pair_add<Mnt4G1> x{levels} + k_bucket_accumulate<Mnt4G1>"
+        # Montgomery products per sorted entry: an affine pair addition is 5 products + 1 squaring (0.76 of a product) including
+        # the 3 of the simultaneous inversion, on 1/2, 1/4, ... of the entries; one divstep inversion (~94 products) per lane and
+        # level over B = slots / 65536 lanes (at least 48); 11 per mixed addition on what is left
+        slots = [windows * n / 2 ** l for l in range(1, levels + 1)]
+        prod_per_entry = sum((5.76 + 94.0 / max(48.0, sl / 65536.0)) / 2 ** l for l, sl in zip(range(1, levels + 1), slots)) + 11.0 / 2 ** levels
+        kernel_name = "k_bucket_accumulate<Mnt4G1>" if levels == 0 else f"k_pair_level<Mnt4G1> x{levels} + k_bucket_accumulate<Mnt4G1>"
         # PMC traffic of the same phase (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh); quoted only
         # while the kernel sources are the ones it was measured on
         traffic, traffic_info = None, None
