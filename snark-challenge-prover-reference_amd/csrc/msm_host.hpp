@@ -14,6 +14,7 @@
 #include "host_field.hpp"
 #include "msm_kernels.hip.h"
 #include "msm_types.hpp"
+#include "msm_sort.hpp"
 #include "mnt753_generators.h"
 
 using namespace mnt753;
@@ -117,7 +118,8 @@ void free_pair_ws(mnt753_bases* b) {
 
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_rank, b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
-                  b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage};
+                  b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage,
+                  b->d_keys_out, b->d_vals_out, b->d_dense, b->d_sort_tmp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   free_pair_ws(b);
   if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
@@ -125,10 +127,17 @@ void free_ws(mnt753_bases* b) {
   b->d_edge_tmp = b->d_edge_flags = nullptr;
   b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
   b->h_wire_out = nullptr; b->d_scalars_stage = nullptr;
+  b->d_keys_out = b->d_vals_out = b->d_dense = nullptr; b->d_sort_tmp = nullptr; b->sort_tmp_bytes = 0;
   b->ws_n = 0;
   b->sorted_cap = 0;
 }
 
+// Sort stage by rocPRIM radix sort (msm_sort.hip) from 2^22 entries on: below, its handful of launches cost more than the
+// atomics it saves.  MNT753_MSM_SORT=atomic / radix overrides.
+inline bool use_radix_sort(uint64_t entries) {
+  if (const char* e = getenv("MNT753_MSM_SORT")) return strcmp(e, "atomic") != 0;
+  return entries >= ((uint64_t)1 << 22);
+}
 template <class C>
 int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   // entries of the sorted list: every bucket padded to a multiple of 2^pair_levels
@@ -147,6 +156,17 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_total, sizeof(uint32_t) * 4));
   HIP_TRY(hipMalloc(&b->d_sorted, sizeof(uint32_t) * sorted_need));
   b->sorted_cap = sorted_need;
+  if (use_radix_sort((uint64_t)p.W * n)) {
+    // radix-sort variant of the sort stage: failing to get its buffers only falls back to the counting sort
+    b->sort_tmp_bytes = msm_sort_temp_bytes((size_t)p.W * n);
+    if (b->sort_tmp_bytes == 0 || hipMalloc(&b->d_keys_out, sizeof(uint32_t) * (size_t)p.W * n) != hipSuccess ||
+        hipMalloc(&b->d_vals_out, sizeof(uint32_t) * (size_t)p.W * n) != hipSuccess || hipMalloc(&b->d_dense, sizeof(uint32_t) * ((size_t)p.n_buckets + 2)) != hipSuccess ||
+        hipMalloc(&b->d_sort_tmp, b->sort_tmp_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      for (void* q : {(void*)b->d_keys_out, (void*)b->d_vals_out, (void*)b->d_dense, b->d_sort_tmp}) if (q) (void)hipFree(q);
+      b->d_keys_out = b->d_vals_out = b->d_dense = nullptr; b->d_sort_tmp = nullptr; b->sort_tmp_bytes = 0;
+    }
+  }
   HIP_TRY(hipMalloc(&b->d_buckets, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
   HIP_TRY(hipMalloc(&b->d_edges, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_bucket, sizeof(uint32_t) * 2 * (size_t)p.n_lanes));
@@ -180,7 +200,13 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
     pW = (754 + pc - 1) / pc;
     if ((uint64_t)pW * n >= 0x7fffffffull) { want_table = false; pc = 0; pW = 1; }   // row index must fit 31 bits
   }
-  HIP_TRY(hipMalloc(&b->d_aff, sizeof(uint32_t) * aff_words<C>() * std::max<size_t>(n, 1) * (size_t)pW));
+  if (hipMalloc(&b->d_aff, sizeof(uint32_t) * aff_words<C>() * std::max<size_t>(n, 1) * (size_t)pW) != hipSuccess) {
+    // no room for the window table (8.9 GB per 2^20 G1 points, 26 GB for Fq3): keep the set usable with one bucket set per window
+    (void)hipGetLastError();
+    if (!want_table) return set_error(MNT753_ENOMEM, "bases_create: device allocation failed");
+    want_table = false; pc = 0; pW = 1;
+    HIP_TRY(hipMalloc(&b->d_aff, sizeof(uint32_t) * aff_words<C>() * std::max<size_t>(n, 1)));
+  }
   HIP_TRY(hipMalloc(&b->d_inf, std::max<size_t>(n, 1)));
   if (n == 0) return 0;
   const uint32_t* src = reinterpret_cast<const uint32_t*>(affine);
@@ -487,19 +513,26 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   const uint32_t* d_aff = p.pre ? b->d_aff : b->d_aff + base_offset * aff_words<C>();
   const uint8_t* d_inf = b->d_inf + base_offset;
   HIP_TRY(hipEventRecord(b->ev[0], st));
-  HIP_TRY(hipMemsetAsync(b->d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
-  const unsigned gb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_rank, b->d_hist, n, p.c, p.W, p.pre ? 0u : p.nb);
-  const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
-  // with pairing levels the offsets count groups of 2^levels entries and the padding of the sorted list is ENTRY_EMPTY
-  const uint32_t pshift = (uint32_t)p.pair_levels;
-  if (pshift) HIP_TRY(hipMemsetAsync(b->d_sorted, 0xff, sizeof(uint32_t) * ((size_t)p.W * n + (size_t)p.n_buckets * (((size_t)1 << pshift) - 1)), st));
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_hist, b->d_offsets, b->d_blocksums, (size_t)p.n_buckets, pshift);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
-  hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total,
-                     (size_t)p.n_buckets);
-  hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_rank, b->d_offsets, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
-                     p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u, pshift);
+  if (b->d_sort_tmp && use_radix_sort((uint64_t)p.W * n)) {
+    if (int rc = msm_sort_radix(C::FR, d_scal, d_inf, n, p, p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u,
+                                reinterpret_cast<uint32_t*>(b->d_digits), b->d_rank, b->d_keys_out, b->d_vals_out, b->d_sort_tmp, b->sort_tmp_bytes, b->d_dense,
+                                b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, st))
+      return rc;
+  } else {
+    HIP_TRY(hipMemsetAsync(b->d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_rank, b->d_hist, n, p.c, p.W, p.pre ? 0u : p.nb);
+    const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    // with pairing levels the offsets count groups of 2^levels entries and the padding of the sorted list is ENTRY_EMPTY
+    const uint32_t pshift = (uint32_t)p.pair_levels;
+    if (pshift) HIP_TRY(hipMemsetAsync(b->d_sorted, 0xff, sizeof(uint32_t) * ((size_t)p.W * n + (size_t)p.n_buckets * (((size_t)1 << pshift) - 1)), st));
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_hist, b->d_offsets, b->d_blocksums, (size_t)p.n_buckets, pshift);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
+    hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total,
+                       (size_t)p.n_buckets);
+    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_rank, b->d_offsets, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
+                       p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u, pshift);
+  }
   HIP_TRY(hipEventRecord(b->ev[1], st));
   // point stages: with the lane-split configuration of the group (Fq2: two lanes per point, Fq3: three) when it has
   // one, otherwise one lane per point.  MNT753_MSM_ACC=vm forces one lane.
