@@ -414,8 +414,8 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
     // accumulate over at most `cap` entries: one round of the machine
     const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, V::F::LANES == 3 ? 21504u : 65536u / (uint32_t)V::F::LANES);
     const uint32_t T2 = (uint32_t)std::max<uint64_t>((cap + lanes_acc - 1) / lanes_acc, 8);
-    hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, src, b->d_sorted2,
-                       b->d_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc);
+    hipLaunchKernelGGL((k_bucket_accumulate<V, true>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, src, b->d_sorted2,
+                       b->d_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
     *acc_lanes = lanes_acc;
     return 0;
   } else {

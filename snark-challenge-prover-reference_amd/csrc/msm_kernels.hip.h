@@ -395,11 +395,17 @@ static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restric
 // with mixed additions.  A run that is neither the first nor the last of the segment is a whole
 // bucket -> written to buckets[].  The first and the last run may continue in a neighbouring lane
 // -> written to edges[2t], edges[2t+1] with their bucket ids.
-template <class C>
+// BLOCKED = false: `bases` holds row-major rows (the window table, or the base set itself).
+// BLOCKED = true:  `bases` holds the four blocked planes the last pairing level wrote ((x | y) x (even | odd slot), plane
+//                  stride `plane_stride` uint4s, see k_pair_level): consecutive entries of a lane then sit in adjacent 16-byte
+//                  pieces of the same sectors, and the level's stores are contiguous KiB instead of 64 partial sectors each.
+__host__ __device__ __forceinline__ size_t blk_index(uint32_t j);
+template <class C, bool BLOCKED = false>
 __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ offsets, uint32_t n_buckets,
                                                              uint32_t* __restrict__ buckets, uint32_t* __restrict__ edges,
-                                                             uint32_t* __restrict__ edge_bucket, uint32_t T, uint32_t n_lanes) {
+                                                             uint32_t* __restrict__ edge_bucket, uint32_t T, uint32_t n_lanes,
+                                                             size_t plane_stride = 0) {
   using F = typename C::F;
   const uint32_t t = logical_lane<typename C::F>();
   if (t >= n_lanes) return;
@@ -439,9 +445,26 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
       do { ++b; next = offsets[b + 1]; } while (next == e);
     }
     uint32_t s = sorted[e];
-    const uint32_t* src = bases + (size_t)(s & 0x7fffffffu) * aff_words<C>();
-    e_load<F>(Q.X, src);
-    e_load<F>(Q.Y, src + F::DEG * FPS_WORDS);
+    if constexpr (BLOCKED) {
+      static_assert(F::DEG == 1 || F::LANES > 1, "blocked rows hold one component per thread");
+      // entries of the blocked list are (row << 1) | sign: with the sign in bit 31 hipcc 7.2 dropped the mask from
+      // (s & 0x7fffffff) >> 7 in the address computation below (s >> 7 fed the 64-bit multiply-add; entries of negated points
+      // faulted 120 GB past the planes)
+      const uint32_t row = s >> 1;
+      s <<= 31;
+      const uint4* px = reinterpret_cast<const uint4*>(bases) + (size_t)(row & 1u) * plane_stride + blk_index((row >> 1) * F::LANES + lane_comp<F>());
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const uint4 vx = px[(size_t)i * 64], vy = px[2 * plane_stride + (size_t)i * 64];
+        Q.X.l[4 * i] = vx.x; Q.X.l[4 * i + 1] = vx.y; Q.X.l[4 * i + 2] = vx.z;
+        Q.Y.l[4 * i] = vy.x; Q.Y.l[4 * i + 1] = vy.y; Q.Y.l[4 * i + 2] = vy.z;
+        if (4 * i + 3 < NL) { Q.X.l[4 * i + 3] = vx.w; Q.Y.l[4 * i + 3] = vy.w; }
+      }
+    } else {
+      const uint32_t* src = bases + (size_t)(s & 0x7fffffffu) * aff_words<C>();
+      e_load<F>(Q.X, src);
+      e_load<F>(Q.Y, src + F::DEG * FPS_WORDS);
+    }
     if (s & 0x80000000u) F::neg(Q.Y, Q.Y);
     int pc = PC_MADD;
     if (acc_zero) {
@@ -497,8 +520,8 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
 //   * rows handed to the NEXT pairing level: four planes (x | y) x (even | odd slot), j = (slot / 2) * LANES + component --
 //     the reader's slot o' takes x1, y1 from the even planes and x2, y2 from the odd planes at j = o' * LANES + component,
 //     the writer's lanes alternate between the two planes and still fill whole 64-byte sectors.
-// Only the two ends stay row-major (224-byte rows): level 1 gathers rows of the window table, the last level writes the
-// rows the accumulate kernel gathers.
+// Only level 1's input stays row-major (224-byte rows of the window table, gathered row-cooperatively); the accumulate kernel
+// reads the last level's planes (a row-major last level cost 1.2 ms at 2^20 in 64-partial-sector stores).
 // Side paths: an odd leftover is copied with its sign flag; equal points are doubled (denominator 2y); opposite points
 // cancel: the slot gets the fixed point D (`gen`, the group generator) and fix_count[bucket] is incremented -- k_pair_fix
 // subtracts fix_count * D from those buckets after the edge merge, so the accumulate kernel never sees an empty slot.
@@ -601,8 +624,8 @@ __device__ __forceinline__ uint32_t fp_from_lds(Fp<M>& r, const uint4* p, uint32
 
 // first: sources are rows of `src_rows` (the window table, row-major) named by the padded entry list; otherwise the four
 //        planes of the previous level at src_planes (plane stride src_stride uint4s).
-// last:  output rows row-major to out_rows plus the entry list out_sorted for the accumulate kernel; otherwise the four
-//        planes at out_planes (stride out_stride).
+// last:  besides the four planes at out_planes (stride out_stride) the level writes the entry list out_sorted (slot o -> row o
+//        of the planes as (o << 1) | sign) that the accumulate kernel (BLOCKED instantiation) reads.
 template <class C, bool first, bool last>
 __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restrict__ src_rows,
                                                       const uint32_t* __restrict__ entries, const uint4* __restrict__ src_planes,
@@ -876,16 +899,12 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     }
     // result (x2, y1) with out_flag (an empty slot only needs its flag; the coordinates written with it are never used)
     if (on) {
-      if constexpr (last) {
-        uint32_t* dst = out_rows + (size_t)o * AW;
-        fp_store_flag(dst + cw, x2, out_flag);
-        fp_store(dst + EW + cw, y1);
-        if (comp == 0) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : (o | ((out_flag & PF_NEG) ? 0x80000000u : 0u));
-      } else {
-        const uint32_t j = (o >> 1) * LN + comp;
-        uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
-        fp_store_blk(px, j, x2, out_flag);
-        fp_store_blk(px + 2 * out_stride, j, y1, 0u);
+      const uint32_t j = (o >> 1) * LN + comp;
+      uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
+      fp_store_blk(px, j, x2, out_flag);
+      fp_store_blk(px + 2 * out_stride, j, y1, 0u);
+      if constexpr (last) {   // the entry list of the accumulate kernel: slot o is row o of the planes
+        if (comp == 0) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : ((o << 1) | ((out_flag & PF_NEG) ? 1u : 0u));
       }
     }
   }
