@@ -403,7 +403,11 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pair_cycles), sizeof(h));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_cycles), z, sizeof(z));
-        if (h[3]) fprintf(stderr, "pair level %d: waves %llu  cycles/wave: forward %.0f  inversion %.0f  backward %.0f  [4] %.0f [5] %.0f [6] %.0f\n", l, h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[3], (double)h[5] / h[3], (double)h[6] / h[3]);
+        unsigned int slots = 1;
+        (void)hipMemcpyFromSymbol(&slots, HIP_SYMBOL(g_pair_slots), sizeof(slots));
+        const double per = (double)h[3] * (slots ? slots : 1);
+        if (h[3]) fprintf(stderr, "pair level %d: waves %llu slots/wave %u  ticks/slot: forward %.0f (dma issue %.0f, store %.0f)  backward %.0f (dma issue %.0f, store %.0f)  inversion/wave %.0f\n", l, h[3], slots,
+                          (double)h[0] / per, (double)h[4] / per, (double)h[5] / per, (double)h[2] / per, (double)h[6] / per, (double)h[7] / per, (double)h[1] / h[3]);
       }
 #endif
       src_planes = reinterpret_cast<const uint4*>(out);

@@ -585,19 +585,34 @@ __device__ __forceinline__ void fp_store_blk(uint4* __restrict__ base, uint32_t 
 // One wave per SIMD, 36 KB of LDS per wave.  Image of a wave (uint4 units):
 //     rows   first level: [point 0 | 1][slot of the wave][quads of the row (x | y) or of x only]   (packed, lane-linear fill)
 //            later levels: [plane x-even | x-odd | y-even | y-odd][quad][thread]                    (own data, already coalesced)
-//     pre    [quad][thread] (the slot's kind rides in its pad word)     entries [2 buffers][2 * slots of the wave]  (first level: fetched two slots ahead)
+//     pre    [quad][thread] (the slot's kind rides in its pad word)     entries [4 buffers][2 * slots of the wave]  (first level: fetched three slots ahead)
+// The forward sweep only needs x: its half-size images alternate between the two halves of `rows`.  MNT753_PAIR_FWD_AHEAD=2
+// fetches them two slots ahead (s_waitcnt vmcnt(14) leaves the younger image in flight); measured: the wait at the top of a
+// slot is ~130 cycles either way, one slot ahead is the default.
 constexpr uint32_t PAIR_IMG_QUADS = 1792;                       // 2 points x 64 lanes x 14 quads (every field: NS * RQ * 2 <= 1792)
-constexpr uint32_t PAIR_LDS_WAVE_QUADS = PAIR_IMG_QUADS + 448 + 64;   // rows, prefix product, entries (2 x 128 u32)
+constexpr uint32_t PAIR_LDS_WAVE_QUADS = PAIR_IMG_QUADS + 448 + 128;  // rows, prefix product, entries (4 x 128 u32)
 constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
+#ifndef MNT753_PAIR_FWD_AHEAD
+#define MNT753_PAIR_FWD_AHEAD 1
+#endif
+#ifndef MNT753_PAIR_OFF_PER_STEP
+#define MNT753_PAIR_OFF_PER_STEP 1     // first level: table offsets of the next slot read per portion (7 registers) instead of per slot (28)
+#endif
 
 #ifdef MNT753_PAIR_TIMING
 // development: cycle totals of k_pair_level per wave (s_memtime): [0] forward, [1] inversion, [2] backward, [3] waves, [4..] ad hoc
 __device__ unsigned long long g_pair_cycles[8];
+__device__ unsigned int g_pair_slots;
 #define PAIR_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PAIR_ACC(i, a, b) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_pair_cycles[i], (unsigned long long)((b) - (a))); } while (0)
+// time spent inside one statement, summed in a register: PAIR_TW(total, statement)
+#define PAIR_TW_DECL(var) unsigned long long var = 0
+#define PAIR_TW(var, ...) do { const unsigned long long t_a = __builtin_readcyclecounter(); __VA_ARGS__; var += __builtin_readcyclecounter() - t_a; } while (0)
 #else
 #define PAIR_T(var)
 #define PAIR_ACC(i, a, b)
+#define PAIR_TW_DECL(var)
+#define PAIR_TW(var, ...) do { __VA_ARGS__; } while (0)
 #endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ void glds16(const void* gsrc, const uint4* lds_dst_wave_uniform) {
@@ -607,6 +622,7 @@ __device__ __forceinline__ void glds4(const void* gsrc, const uint32_t* lds_dst_
   __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr_t)lds_dst_wave_uniform, 4, 0, 0);
 }
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); }     // vmcnt(0)
+__device__ __forceinline__ void wait_vm14() { __builtin_amdgcn_s_waitcnt(0x0f7e); asm volatile("" ::: "memory"); }    // vmcnt(14)
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); asm volatile("" ::: "memory"); }   // lgkmcnt(0)
 template <int M>
 __device__ __forceinline__ uint32_t fp_from_lds(Fp<M>& r, const uint4* p, uint32_t stride) {   // 7 quads at p, p + stride, ...
@@ -644,11 +660,14 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   constexpr uint32_t RQ = 14u * F::DEG;                   // quads of a table row (x | y)
   constexpr uint32_t XQ = 7u * F::DEG;                    // quads of its x coordinate
   static_assert(2 * NS * RQ <= PAIR_IMG_QUADS, "row image");
+  // first level of a base field: the table offsets of the next slot's pieces are read out of the entry image ahead of the
+  // loads (per portion).  The lane-split fields keep a ds_read in front of every piece: their multiplier leaves no registers.
+  constexpr bool PRELOAD = first && LN == 1;
   extern __shared__ uint4 pair_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint4* img = pair_lds + (size_t)wave * PAIR_LDS_WAVE_QUADS;
   uint4* pre_img = img + PAIR_IMG_QUADS;
-  uint32_t* ent_img = reinterpret_cast<uint32_t*>(pre_img + 448);   // [2][128]
+  uint32_t* ent_img = reinterpret_cast<uint32_t*>(pre_img + 448);   // [4][128]
 
   const uint32_t S = offsG[n_buckets] << shift;          // slots of this level (shift = levels still to come)
   // batch length from the ACTUAL number of slots (the host only knows the worst case): witness vectors full of zero and one
@@ -681,7 +700,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   };
   // LDS-DMA instruction k of the rows of iteration `it` (entries already in ent_img[buf]); xonly = x coordinates only (forward
   // sweep).  first: 2 * NS * rq quads in image order, 64 per instruction; later levels: one instruction per (plane, quad).
-  auto issue_row_piece = [=](uint32_t it, uint32_t buf, uint32_t k, auto xonly_c) __attribute__((always_inline)) {
+  auto issue_row_piece = [=](uint32_t it, uint32_t buf, uint32_t k, auto xonly_c, uint4* im) __attribute__((always_inline)) {
     constexpr bool xonly = decltype(xonly_c)::value;
     if constexpr (first) {
       constexpr uint32_t rq = xonly ? XQ : RQ;
@@ -691,60 +710,110 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
       const uint32_t e = ent_img[buf * 128u + 2u * s + p];
       const uint32_t r = e == ENTRY_EMPTY ? 0u : (e & 0x7fffffffu);
-      glds16(table + (size_t)r * RQ + q, img + 64u * k);
+      glds16(table + (size_t)r * RQ + q, im + 64u * k);
     } else {
       const uint32_t o = min(it * NLe + (lane_on ? t : t0w), S - 1u);
       const uint32_t j = o * LN + comp;
       const uint32_t pl = k / 7u, q = k - pl * 7u;
-      glds16(src_planes + blk_index(j) + (size_t)pl * src_stride + (size_t)q * 64, img + k * 64u);
+      glds16(src_planes + blk_index(j) + (size_t)pl * src_stride + (size_t)q * 64, im + k * 64u);
     }
   };
   constexpr uint32_t ROW_PIECES_X = first ? (2u * NS * XQ + 63u) / 64u : 14u;
   constexpr uint32_t ROW_PIECES = first ? (2u * NS * RQ + 63u) / 64u : 28u;
-  auto issue_rows = [=](uint32_t it, uint32_t buf, auto xonly_c) __attribute__((always_inline)) {
+  auto issue_rows = [=](uint32_t it, uint32_t buf, auto xonly_c, uint4* im) __attribute__((always_inline)) {
     constexpr uint32_t n = decltype(xonly_c)::value ? ROW_PIECES_X : ROW_PIECES;
 #pragma unroll
-    for (uint32_t k = 0; k < n; ++k) issue_row_piece(it, buf, k, xonly_c);
+    for (uint32_t k = 0; k < n; ++k) issue_row_piece(it, buf, k, xonly_c, im);
+  };
+  // first level: the table offsets (uint4 units) of this lane's pieces of one slot, all read out of ent_img[buf] in one go.
+  // A ds_read + s_waitcnt lgkmcnt(0) in front of EVERY LDS-DMA instruction cost a quarter of the level (the LDS queue is
+  // busy with the DMA's own writes); the offsets of the next slot now sit in registers before the first piece is issued.
+  auto row_offset = [=](uint32_t buf, uint32_t k) __attribute__((always_inline)) {      // piece k of a full-row image
+    const uint32_t i = min(64u * k + lane, 2u * NS * RQ - 1u);
+    const uint32_t rs = i / RQ, q = i - rs * RQ;
+    const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
+    const uint32_t e = ent_img[buf * 128u + 2u * s + p];
+    return (e == ENTRY_EMPTY ? 0u : (e & 0x7fffffffu)) * RQ + q;
+  };
+  auto load_row_offsets = [=](uint32_t buf, auto xonly_c, uint32_t (&off)[ROW_PIECES]) __attribute__((always_inline)) {
+    constexpr bool xonly = decltype(xonly_c)::value;
+    constexpr uint32_t rq = xonly ? XQ : RQ;
+    constexpr uint32_t total = 2u * NS * rq;
+    constexpr uint32_t n = xonly ? ROW_PIECES_X : ROW_PIECES;
+#pragma unroll
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t i = min(64u * k + lane, total - 1u);
+      const uint32_t rs = i / rq, q = i - rs * rq;
+      const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
+      const uint32_t e = ent_img[buf * 128u + 2u * s + p];
+      const uint32_t r = e == ENTRY_EMPTY ? 0u : (e & 0x7fffffffu);
+      off[k] = r * RQ + q;
+    }
   };
   // this thread's operands of the current slot, out of the image
-  auto read_rows = [=](uint32_t buf, auto xonly_c, uint32_t& f0, uint32_t& f1, E& x1, E& y1, E& x2, E& y2) __attribute__((always_inline)) {
+  auto read_rows = [=](uint32_t buf, auto xonly_c, const uint4* im, uint32_t& f0, uint32_t& f1, E& x1, E& y1, E& x2, E& y2) __attribute__((always_inline)) {
     constexpr bool xonly = decltype(xonly_c)::value;
     if constexpr (first) {
       constexpr uint32_t rq = xonly ? XQ : RQ;
       const uint32_t e0 = ent_img[buf * 128u + 2u * sl], e1 = ent_img[buf * 128u + 2u * sl + 1u];
       f0 = e0 == ENTRY_EMPTY ? PF_EMPTY : (e0 >> 31) * PF_NEG;
       f1 = e1 == ENTRY_EMPTY ? PF_EMPTY : (e1 >> 31) * PF_NEG;
-      const uint4* p0 = img + (size_t)sl * rq + comp * 7u;
-      const uint4* p1 = img + (size_t)(NS + sl) * rq + comp * 7u;
+      const uint4* p0 = im + (size_t)sl * rq + comp * 7u;
+      const uint4* p1 = im + (size_t)(NS + sl) * rq + comp * 7u;
       (void)fp_from_lds(x1, p0, 1u);
       (void)fp_from_lds(x2, p1, 1u);
       if constexpr (!xonly) { (void)fp_from_lds(y1, p0 + XQ, 1u); (void)fp_from_lds(y2, p1 + XQ, 1u); }
     } else {
-      f0 = fp_from_lds(x1, img + lane, 64u);
-      f1 = fp_from_lds(x2, img + 7u * 64u + lane, 64u);
-      if constexpr (!xonly) { (void)fp_from_lds(y1, img + 14u * 64u + lane, 64u); (void)fp_from_lds(y2, img + 21u * 64u + lane, 64u); }
+      f0 = fp_from_lds(x1, im + lane, 64u);
+      f1 = fp_from_lds(x2, im + 7u * 64u + lane, 64u);
+      if constexpr (!xonly) { (void)fp_from_lds(y1, im + 14u * 64u + lane, 64u); (void)fp_from_lds(y2, im + 21u * 64u + lane, 64u); }
     }
   };
 
   // ---- forward: prefix products of the denominators, kinds
   PAIR_T(tc0);
+  PAIR_TW_DECL(tw_a); PAIR_TW_DECL(tw_b); PAIR_TW_DECL(tw_c); PAIR_TW_DECL(tw_d);
+  constexpr uint32_t XIMG = PAIR_IMG_QUADS / 2u;          // one x-only image (14 pieces of 64 quads)
+  static_assert(ROW_PIECES_X * 64u <= XIMG, "x image");
+  // x image of slot `it` -> half (it & 1) of the row image; first level: offsets from the entries in ent_img[it & 3]
+  auto issue_x = [=](uint32_t it) __attribute__((always_inline)) {
+    uint4* im = img + (it & 1u) * XIMG;
+    issue_rows(it, it & 3u, std::true_type{}, im);
+  };
+  constexpr uint32_t AH = MNT753_PAIR_FWD_AHEAD;          // slots between the issue of an x image and its use
   if constexpr (first) {
     issue_entries(0, 0);
-    wait_vm0();
     issue_entries(min(1u, n_it - 1u), 1);
+    if constexpr (AH == 2u) issue_entries(min(2u, n_it - 1u), 2);
+    wait_vm0();
   }
-  issue_rows(0, 0, std::true_type{});
+  issue_x(0);
+  if constexpr (AH == 2u) { if (n_it > 1u) issue_x(1); }
   for (uint32_t it = 0; it < n_it; ++it) {
     const uint32_t o = it * NLe + t;
     const bool on = lane_on && o < S;
     uint32_t f0, f1;
-    wait_vm0();
-    read_rows(it & 1u, std::true_type{}, f0, f1, x1, y1, x2, y2);
+    // the image of this slot is complete; the 14 loads of the next slot's image (issued after everything else of the previous
+    // iteration) may stay in flight -- vmcnt counts in issue order
+    if (AH == 2u && it + 1u < n_it) wait_vm14(); else wait_vm0();
+    read_rows(it & 3u, std::true_type{}, img + (it & 1u) * XIMG, f0, f1, x1, y1, x2, y2);
+    const bool ahead = it + AH < n_it;
+    uint32_t off[ROW_PIECES];
+    if constexpr (PRELOAD) { if (ahead) load_row_offsets((it + AH) & 3u, std::true_type{}, off); }
     wait_lgkm0();
-    if (it + 1u < n_it) {
-      if constexpr (first) issue_entries(min(it + 2u, n_it - 1u), it & 1u);
-      issue_rows(it + 1u, (it + 1u) & 1u, std::true_type{});
-    }
+    // image of slot it + AH into the half it will be read from (entries first, the 14 row loads last: see the wait above).
+    // One slot ahead: at once, the half is free; two slots ahead: after this slot's stores, into the half just read.
+    auto issue_ahead = [=](const uint32_t (&off)[ROW_PIECES]) __attribute__((always_inline)) {
+      uint4* im = img + ((it + AH) & 1u) * XIMG;
+      if constexpr (first) issue_entries(min(it + AH + 1u, n_it - 1u), (it + AH + 1u) & 3u);
+      if constexpr (PRELOAD) {
+#pragma unroll
+        for (uint32_t k = 0; k < ROW_PIECES_X; ++k) glds16(table + off[k], im + 64u * k);
+      } else {
+        issue_rows(it + AH, (it + AH) & 3u, std::true_type{}, im);
+      }
+    };
+    if constexpr (AH == 1u) { if (ahead) issue_ahead(off); }
     uint32_t kind;
     if (!on || (f0 & PF_EMPTY)) kind = PK_EMPTY;
     else if (f1 & PF_EMPTY) kind = PK_SINGLE;
@@ -766,7 +835,13 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       }
     }
     // the prefix product travels with the slot's kind in its pad word (read back by the thread that wrote it)
-    if (on) fp_store_blk(prefix_ws, o * LN + comp, run, kind);
+    PAIR_TW(tw_b, if (on) fp_store_blk(prefix_ws, o * LN + comp, run, kind));
+    PAIR_T(tfa0);
+    asm volatile("" ::: "memory");
+    if constexpr (AH == 2u) { if (ahead) issue_ahead(off); }
+#ifdef MNT753_PAIR_TIMING
+    tw_a += __builtin_readcyclecounter() - tfa0;
+#endif
     if (kind <= PK_CANCEL) {
       F::mul(tmp, run, den);
       run = tmp;
@@ -780,7 +855,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   // piece `idx` of the LDS-DMA of iteration `it`: ROW_PIECES row pieces, then the 7 quads of the prefix product
   constexpr uint32_t BWD_PIECES = ROW_PIECES + 7u;
   auto issue_bwd_piece = [=](uint32_t it, uint32_t buf, uint32_t idx) __attribute__((always_inline)) {
-    if (idx < ROW_PIECES) issue_row_piece(it, buf, idx, std::false_type{});
+    if (idx < ROW_PIECES) issue_row_piece(it, buf, idx, std::false_type{}, img);
     else if (idx < BWD_PIECES) {
       const uint32_t o = min(it * NLe + (lane_on ? t : t0w), S - 1u);
       const uint32_t q = idx - ROW_PIECES;
@@ -797,18 +872,22 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     issue_entries(n_it > 1u ? n_it - 2u : 0u, 1);
   }
   issue_bwd(n_it - 1u, 0);
+  wait_vm0();
   for (uint32_t n = 0; n < n_it; ++n) {
     const uint32_t it = n_it - 1u - n;
     const uint32_t o = it * NLe + t;
     const bool on = lane_on && o < S;
     uint32_t f0, f1;
     E pre;
-    wait_vm0();
-    read_rows(n & 1u, std::false_type{}, f0, f1, x1, y1, x2, y2);
+    read_rows(n & 1u, std::false_type{}, img, f0, f1, x1, y1, x2, y2);
     const uint32_t kflag = fp_from_lds(pre, pre_img + lane, 64u);
     const uint32_t kind = on ? kflag : (uint32_t)PK_EMPTY;
-    wait_lgkm0();
     const bool more = n + 1u < n_it;
+    // blocked index (uint4 units) of the next slot's element: the per-lane part of the addresses of its planes and prefix product
+    const uint32_t vb_next = more ? (uint32_t)blk_index(min((it - 1u) * NLe + (lane_on ? t : t0w), S - 1u) * LN + comp) : 0u;
+    uint32_t off[ROW_PIECES];
+    if constexpr (PRELOAD && !MNT753_PAIR_OFF_PER_STEP) { if (more) load_row_offsets((n + 1u) & 1u, std::false_type{}, off); }
+    wait_lgkm0();
     if constexpr (first) { if (more) issue_entries(it >= 2u ? it - 2u : 0u, n & 1u); }
     const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
     uint32_t out_flag = PF_EMPTY;
@@ -843,12 +922,67 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     // the address path needs to take them (~300 cycles each for gathered rows).
     {
       E opa, opb, res;
-      constexpr uint32_t PER_STEP = (BWD_PIECES + 4u) / 5u;
+      // the image of the next slot is issued during the first DMA_STEPS products: gathered rows in five small portions (each
+      // instruction holds the wave while the address path takes it), own planes in three (12.2 -> 11.1 ms and 5.36 -> 5.21 ms)
+      constexpr uint32_t DMA_STEPS = (first || LN > 1) ? 5u : 3u;
+      constexpr bool CONST_PIECES = first || LN == 1;      // measured per instantiation: the lane-split later levels keep the plain loop
+      constexpr uint32_t PER_STEP = (BWD_PIECES + DMA_STEPS - 1u) / DMA_STEPS;
 #pragma nounroll
       for (int step = 0; step < 5; ++step) {
-        if (more) {
-          for (uint32_t u = 0; u < PER_STEP; ++u) issue_bwd_piece(it - 1u, (n + 1u) & 1u, (uint32_t)step * PER_STEP + u);
+        PAIR_T(tdm0);
+        if constexpr (!CONST_PIECES) {
+          if (more) for (uint32_t u = 0; u < PER_STEP; ++u) issue_bwd_piece(it - 1u, (n + 1u) & 1u, (uint32_t)step * PER_STEP + u);
+        } else if (more && (uint32_t)step < DMA_STEPS) {
+          // portion `step` of the next slot's image.  The pieces are named by constants (so that `off` stays in registers and
+          // plane / quad offsets are scalar constants), and the per-lane part of every address passes through an opaque move:
+          // the 64-bit addresses are formed here, one VALU instruction each, not hoisted out of the step loop (35 live
+          // addresses would not fit the register file) and not recomputed from the slot number either.
+          auto portion = [=](auto step_c, const uint32_t (&off)[ROW_PIECES], uint32_t vb) __attribute__((always_inline)) {
+            constexpr uint32_t base = decltype(step_c)::value * PER_STEP;
+            uint32_t offp[PER_STEP];
+            if constexpr (PRELOAD && MNT753_PAIR_OFF_PER_STEP) {
+              // the table offsets of this portion out of the entry image, one wait for all of them
+#pragma unroll
+              for (uint32_t u = 0; u < PER_STEP; ++u) offp[u] = base + u < ROW_PIECES ? row_offset((n + 1u) & 1u, base + u) : 0u;
+              wait_lgkm0();
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < PER_STEP; ++u) {
+              const uint32_t idx = base + u;
+              if (idx < ROW_PIECES) {
+                if constexpr (PRELOAD) {
+                  uint32_t o = MNT753_PAIR_OFF_PER_STEP ? offp[u] : off[idx < ROW_PIECES ? idx : 0u];
+                  asm volatile("" : "+v"(o));
+                  glds16(table + o, img + 64u * idx);
+                } else if constexpr (first) {
+                  uint32_t k = idx;
+                  asm volatile("" : "+s"(k));
+                  issue_row_piece(it - 1u, (n + 1u) & 1u, k, std::false_type{}, img);
+                } else {
+                  const uint32_t pl = idx / 7u, q = idx - pl * 7u;
+                  uint32_t o = vb;
+                  asm volatile("" : "+v"(o));
+                  glds16(src_planes + (size_t)pl * src_stride + (size_t)q * 64 + o, img + 64u * idx);
+                }
+              } else if (idx < BWD_PIECES) {
+                const uint32_t q = idx - ROW_PIECES;
+                uint32_t o = vb;
+                asm volatile("" : "+v"(o));
+                glds16(prefix_ws + (size_t)q * 64 + o, pre_img + q * 64u);
+              }
+            }
+          };
+          switch (step) {
+            case 0: portion(std::integral_constant<uint32_t, 0>{}, off, vb_next); break;
+            case 1: portion(std::integral_constant<uint32_t, 1>{}, off, vb_next); break;
+            case 2: portion(std::integral_constant<uint32_t, 2>{}, off, vb_next); break;
+            case 3: portion(std::integral_constant<uint32_t, 3>{}, off, vb_next); break;
+            default: portion(std::integral_constant<uint32_t, 4>{}, off, vb_next); break;
+          }
         }
+#ifdef MNT753_PAIR_TIMING
+        tw_c += __builtin_readcyclecounter() - tdm0;
+#endif
         switch (step) {
           case 0: opa = inv; opb = pre; break;
           case 1: opa = inv; opb = den; break;
@@ -897,7 +1031,12 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
         }
       }
     }
-    // result (x2, y1) with out_flag (an empty slot only needs its flag; the coordinates written with it are never used)
+    // result (x2, y1) with out_flag (an empty slot only needs its flag; the coordinates written with it are never used).
+    // The wait for the next slot's image stands BEFORE the stores: vmcnt counts loads and stores alike on gfx9, and a wait at
+    // the top of the next slot would sit out the write latency of the fourteen stores issued just ahead of it.  Here it
+    // covers the DMA (last portion one product old) and the previous slot's stores (a whole slot old).
+    wait_vm0();
+    PAIR_T(tst0);
     if (on) {
       const uint32_t j = (o >> 1) * LN + comp;
       uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
@@ -907,9 +1046,16 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
         if (comp == 0) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : ((o << 1) | ((out_flag & PF_NEG) ? 1u : 0u));
       }
     }
+#ifdef MNT753_PAIR_TIMING
+    tw_d += __builtin_readcyclecounter() - tst0;
+#endif
   }
   PAIR_T(tc3);
   PAIR_ACC(0, tc0, tc1); PAIR_ACC(1, tc1, tc2); PAIR_ACC(2, tc2, tc3); PAIR_ACC(3, 0ull, 1ull);
+#ifdef MNT753_PAIR_TIMING
+  PAIR_ACC(4, 0ull, tw_a); PAIR_ACC(5, 0ull, tw_b); PAIR_ACC(6, 0ull, tw_c); PAIR_ACC(7, 0ull, tw_d);
+  if ((threadIdx.x & 63u) == 0 && blockIdx.x == 0 && wave == 0) g_pair_slots = n_it;
+#endif
 }
 
 template <class C>
