@@ -592,6 +592,9 @@ __device__ __forceinline__ void fp_store_blk(uint4* __restrict__ base, uint32_t 
 constexpr uint32_t PAIR_IMG_QUADS = 1792;                       // 2 points x 64 lanes x 14 quads (every field: NS * RQ * 2 <= 1792)
 constexpr uint32_t PAIR_LDS_WAVE_QUADS = PAIR_IMG_QUADS + 448 + 128;  // rows, prefix product, entries (4 x 128 u32)
 constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
+#ifndef MNT753_PAIR_DMA_STEPS_LATER
+#define MNT753_PAIR_DMA_STEPS_LATER 3
+#endif
 #ifndef MNT753_PAIR_FWD_AHEAD
 #define MNT753_PAIR_FWD_AHEAD 1
 #endif
@@ -924,15 +927,12 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       E opa, opb, res;
       // the image of the next slot is issued during the first DMA_STEPS products: gathered rows in five small portions (each
       // instruction holds the wave while the address path takes it), own planes in three (12.2 -> 11.1 ms and 5.36 -> 5.21 ms)
-      constexpr uint32_t DMA_STEPS = (first || LN > 1) ? 5u : 3u;
-      constexpr bool CONST_PIECES = first || LN == 1;      // measured per instantiation: the lane-split later levels keep the plain loop
+      constexpr uint32_t DMA_STEPS = first ? 5u : MNT753_PAIR_DMA_STEPS_LATER;
       constexpr uint32_t PER_STEP = (BWD_PIECES + DMA_STEPS - 1u) / DMA_STEPS;
 #pragma nounroll
       for (int step = 0; step < 5; ++step) {
         PAIR_T(tdm0);
-        if constexpr (!CONST_PIECES) {
-          if (more) for (uint32_t u = 0; u < PER_STEP; ++u) issue_bwd_piece(it - 1u, (n + 1u) & 1u, (uint32_t)step * PER_STEP + u);
-        } else if (more && (uint32_t)step < DMA_STEPS) {
+        if (more && (uint32_t)step < DMA_STEPS) {
           // portion `step` of the next slot's image.  The pieces are named by constants (so that `off` stays in registers and
           // plane / quad offsets are scalar constants), and the per-lane part of every address passes through an opaque move:
           // the 64-bit addresses are formed here, one VALU instruction each, not hoisted out of the step loop (35 live
