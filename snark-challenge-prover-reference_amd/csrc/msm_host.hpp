@@ -362,6 +362,11 @@ MsmPlan plan_for(const mnt753_bases* b, size_t n) {
   p.pair_levels = b->no_pair ? 0 : pair_levels_for<C>((uint64_t)p.W * n);
   // the padded list must keep 32-bit slot indices
   while (p.pair_levels > 0 && (uint64_t)p.W * n + (uint64_t)p.n_buckets * (((uint64_t)1 << p.pair_levels) - 1) >= 0xfffffff0ull) --p.pair_levels;
+  // base fields: the first level keeps table offsets in 32-bit registers (uint4 units, 14 per row) -- a table of 64 GiB or more
+  // (2^23 G1 points with 38 windows) goes through the accumulate kernel alone
+  if (point_lanes<C>() == 1 && C::F::DEG == 1 && (uint64_t)p.W * std::max<uint64_t>(b->n, n) * 14u >= 0xffffffffull) p.pair_levels = 0;
+  // every field: blocked indices of level-1 slots (7 uint4 per element and lane) are 32-bit in the level kernels
+  if (p.pair_levels > 0 && pair_cap1(p, n) * (uint64_t)point_lanes<C>() * 7u >= 0xffffff00ull) p.pair_levels = 0;
   return p;
 }
 template <class V, class C>
