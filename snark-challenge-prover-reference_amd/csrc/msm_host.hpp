@@ -480,6 +480,19 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
     const uint32_t k = (uint32_t)p.c - 1u, NS = p.n_sets;
     for (uint32_t step = 0; step < k; ++step) {
       const uint64_t items = (uint64_t)NS * red_items(k, step);
+      // narrow steps of a base field: two lanes per addition (8 sequential products instead of 14), MNT753_REDUCE_PAIR=0 turns it off
+      static const bool pair_tail = !(getenv("MNT753_REDUCE_PAIR") && atoi(getenv("MNT753_REDUCE_PAIR")) == 0);
+      if constexpr (C::F::LANES == 1 && C::F::DEG == 1) {
+        if (pair_tail && 2 * items <= 65536) {
+          hipLaunchKernelGGL((k_reduce_step_pair<C>), dim3((unsigned)((2 * items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
+          continue;
+        }
+      } else if constexpr (V::F::LANES == 2) {
+        if (pair_tail && (mask & 4u) && 4 * items <= 65536) {
+          hipLaunchKernelGGL((k_reduce_step_pair<V>), dim3((unsigned)((4 * items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
+          continue;
+        }
+      }
       if (mask & 4u)
         hipLaunchKernelGGL((k_reduce_step<V>), dim3(blocks_for<typename V::F>(items)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
       else

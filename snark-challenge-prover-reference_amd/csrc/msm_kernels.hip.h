@@ -1208,6 +1208,124 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_reduce_step(const uint32
   pt_vm<C, true>(acc, Q, pc);
   proj_store<C>(dst, acc);
 }
+// The same step with TWO lanes per addition, for the narrow steps (one addition deep whatever their width: 15 of the 19 steps
+// of a 2^19-bucket reduction, 78 us each).  The 12 products + 2 squarings of a projective addition are five dependency
+// levels deep; two lanes run them as 3 + 1 + 2 + 1 + 1 = 8 sequential products: the odd lane holds the operands swapped, so
+// the first level is the same code in both lanes, later levels pick their operands by parity and exchange one element each
+// (ds_bpermute with the neighbour lane).  Same group element as pt_vm<PC_ADD> (mnt4753_g1.cpp:134-207: add-1998-cmo-2);
+// identities are resolved before, equal points (a doubling) fall back to the VM in the even half.  Base fields, and the
+// two-lane Fq2 with four lanes per addition.
+template <int M, int DIST>
+__device__ __forceinline__ void fp_pair_xchg(Fp<M>& r, const Fp<M>& a) {      // the value of lane ^ DIST
+  const int src = (int)(((threadIdx.x & 63u) ^ (uint32_t)DIST) << 2);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)a.l[i]);
+}
+template <int M>
+__device__ __forceinline__ void fp_pick(Fp<M>& r, bool c, const Fp<M>& a, const Fp<M>& b) {   // c ? a : b
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+}
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_reduce_step_pair(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
+                                                            uint32_t* __restrict__ A, uint32_t* __restrict__ G, uint32_t n_sets, uint32_t k, uint32_t s) {
+  using F = typename C::F;
+  using E = typename F::E;
+  static_assert((F::LANES == 1 && F::DEG == 1) || F::LANES == 2, "base fields and the two-lane Fq2");
+  constexpr int M = F::MOD;
+  constexpr uint32_t LN = F::LANES;            // lanes per point: an addition takes 2 * LN lanes, partners are LN apart
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool odd = ((tid / LN) & 1u) != 0;
+  const uint32_t per_set = red_items(k, s);
+  // both halves of a pair always run together (the exchanges need the neighbour): pairs beyond the list repeat the last item
+  const uint32_t n_items = n_sets * per_set;
+  const bool live = tid / (2u * LN) < n_items;
+  const uint32_t t = live ? tid / (2u * LN) : n_items - 1u;
+  constexpr int PW = proj_words<C>();
+  const uint32_t set = t / per_set, r0 = t - set * per_set;
+  const uint32_t nb = 1u << k, nh = 1u << (k - s - 1);
+  const uint32_t* a_src = s == 0 ? buckets + (size_t)set * nb * PW : A + ((size_t)set * nb + red_off_a(k, s)) * PW;
+  uint32_t i0, i1;
+  const uint32_t* src;
+  uint32_t* dst;
+  if (r0 < nh) {
+    i0 = 2u * r0; i1 = i0 + 1u; src = a_src;
+    dst = A + ((size_t)set * nb + red_off_a(k, s + 1) + r0) * PW;
+  } else {
+    const uint32_t sh = k - s - 2, r = r0 - nh, l = r >> sh, j = r & ((1u << sh) - 1u);
+    uint32_t* g = G + ((size_t)set * nb + red_off_g(k, l)) * PW;
+    const uint32_t half = 1u << (k - l - 2);
+    if (l == s) {
+      i0 = 4u * j + 1u; i1 = i0 + 2u; src = a_src;
+      dst = g + (size_t)j * PW;
+    } else {
+      i0 = 2u * j; i1 = i0 + 1u; src = g + (size_t)(((s - l - 1u) & 1u) * half) * PW;
+      dst = g + (size_t)(((s - l) & 1u) * half + j) * PW;
+    }
+  }
+  // S = this lane's first operand, T = its second: the odd lane holds them swapped
+  const uint32_t iS = odd ? i1 : i0, iT = odd ? i0 : i1;
+  const bool from_buckets = s == 0 && src == a_src;
+  const bool eS = from_buckets && offsets[(size_t)set * nb + iS + 1] == offsets[(size_t)set * nb + iS];
+  const bool eT = from_buckets && offsets[(size_t)set * nb + iT + 1] == offsets[(size_t)set * nb + iT];
+  Proj<C> S, T;
+  if (eS) pt_set_zero(S); else proj_load<C>(S, src + (size_t)iS * PW);
+  if (eT) pt_set_zero(T); else proj_load<C>(T, src + (size_t)iT * PW);
+  const bool zS = pt_is_zero(S), zT = pt_is_zero(T);
+  // level 1: X1Z2, Y1Z2, Z1Z2 (even) | X2Z1, Y2Z1, Z1Z2 (odd)
+  E t1, t2, t3, o, x1z2, x2z1, y1z2, y2z1, u, v;
+  F::mul(t1, S.X, T.Z);
+  F::mul(t2, S.Y, T.Z);
+  F::mul(t3, S.Z, T.Z);
+  fp_pair_xchg<M, (int)LN>(o, t1); fp_pick<M>(x1z2, odd, o, t1); fp_pick<M>(x2z1, odd, t1, o);
+  fp_pair_xchg<M, (int)LN>(o, t2); fp_pick<M>(y1z2, odd, o, t2); fp_pick<M>(y2z1, odd, t2, o);
+  F::sub(v, x2z1, x1z2);
+  F::sub(u, y2z1, y1z2);
+  const bool same = F::is_zero(u) && F::is_zero(v);
+  // level 2: vv (even) | uu (odd)
+  E sq, vv, uu, vvv, m, R, uuZ, Aq, RA;
+  fp_pick<M>(m, odd, u, v);
+  if constexpr (has_sqr<F>::value) F::sqr(sq, m); else F::mul(sq, m, m);
+  fp_pair_xchg<M, (int)LN>(o, sq); fp_pick<M>(vv, odd, o, sq); fp_pick<M>(uu, odd, sq, o);
+  // level 3: vvv (both), R = vv X1Z2 (even) | uu Z1Z2 (odd)
+  F::mul(vvv, v, vv);
+  {
+    E a, b;
+    fp_pick<M>(a, odd, uu, vv); fp_pick<M>(b, odd, t3, x1z2);
+    F::mul(m, a, b);
+  }
+  fp_pair_xchg<M, (int)LN>(o, m); fp_pick<M>(R, odd, o, m); fp_pick<M>(uuZ, odd, m, o);
+  F::sub(Aq, uuZ, vvv); F::sub(Aq, Aq, R); F::sub(Aq, Aq, R);      // A = uu Z1Z2 - vvv - 2R
+  F::sub(RA, R, Aq);
+  // level 4: X3 = v A (even) | vvv Y1Z2 (odd)
+  E m3, m4, o3, o4;
+  {
+    E a, b;
+    fp_pick<M>(a, odd, vvv, v); fp_pick<M>(b, odd, y1z2, Aq);
+    F::mul(m3, a, b);
+  }
+  fp_pair_xchg<M, (int)LN>(o3, m3);
+  // level 5: u (R - A) (even) | Z3 = vvv Z1Z2 (odd)
+  {
+    E a, b;
+    fp_pick<M>(a, odd, vvv, u); fp_pick<M>(b, odd, t3, RA);
+    F::mul(m4, a, b);
+  }
+  fp_pair_xchg<M, (int)LN>(o4, m4);
+  if (odd || !live) return;
+  Proj<C> out;
+  if (zS || zT) {                       // identities: S + 0 = S, 0 + T = T
+    out = zT ? S : T;
+  } else if (same) {                    // equal points: the VM's addition turns into its doubling
+    out = S;
+    pt_vm<C, true>(out, T, PC_ADD);
+  } else {
+    out.X = m3;
+    F::sub(out.Y, m4, o3);
+    out.Z = o4;
+  }
+  proj_store<C>(dst, out);
+}
 // the k + 1 points the host combines, per bucket set: out[set][0] = T = A_k[0], out[set][1 + l] = G_l
 template <class C>
 __global__ void __launch_bounds__(64) k_reduce_collect(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
