@@ -482,13 +482,19 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
       const uint64_t items = (uint64_t)NS * red_items(k, step);
       // narrow steps of a base field: two lanes per addition (8 sequential products instead of 14), MNT753_REDUCE_PAIR=0 turns it off
       static const bool pair_tail = !(getenv("MNT753_REDUCE_PAIR") && atoi(getenv("MNT753_REDUCE_PAIR")) == 0);
+      static const uint64_t pair_max = getenv("MNT753_REDUCE_PAIR_MAX") ? strtoull(getenv("MNT753_REDUCE_PAIR_MAX"), nullptr, 10) : 65536;   // lanes
       if constexpr (C::F::LANES == 1 && C::F::DEG == 1) {
-        if (pair_tail && 2 * items <= 65536) {
+        static const bool line = !(getenv("MNT753_REDUCE_LINE") && atoi(getenv("MNT753_REDUCE_LINE")) == 0);   // wide steps: straight-line addition instead of the VM's
+        if (line && 2 * items > pair_max) {
+          hipLaunchKernelGGL((k_reduce_step_line<C>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
+          continue;
+        }
+        if (pair_tail && 2 * items <= pair_max) {
           hipLaunchKernelGGL((k_reduce_step_pair<C>), dim3((unsigned)((2 * items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
           continue;
         }
       } else if constexpr (V::F::LANES == 2) {
-        if (pair_tail && (mask & 4u) && 4 * items <= 65536) {
+        if (pair_tail && (mask & 4u) && 4 * items <= pair_max) {
           hipLaunchKernelGGL((k_reduce_step_pair<V>), dim3((unsigned)((4 * items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
           continue;
         }

@@ -1326,6 +1326,70 @@ __global__ void __launch_bounds__(256, 1) k_reduce_step_pair(const uint32_t* __r
   }
   proj_store<C>(dst, out);
 }
+// One lane per addition without the VM: the same formulas in a straight line (14 products), for the wide steps of a base field
+// (a round of the VM's addition takes ~90 us, its switch machine and operand routing included).
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_reduce_step_line(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
+                                                            uint32_t* __restrict__ A, uint32_t* __restrict__ G, uint32_t n_sets, uint32_t k, uint32_t s) {
+  using F = typename C::F;
+  using E = typename F::E;
+  static_assert(F::LANES == 1 && F::DEG == 1, "base fields");
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t per_set = red_items(k, s);
+  if (t >= n_sets * per_set) return;
+  constexpr int PW = proj_words<C>();
+  const uint32_t set = t / per_set, r0 = t - set * per_set;
+  const uint32_t nb = 1u << k, nh = 1u << (k - s - 1);
+  const uint32_t* a_src = s == 0 ? buckets + (size_t)set * nb * PW : A + ((size_t)set * nb + red_off_a(k, s)) * PW;
+  uint32_t i0, i1;
+  const uint32_t* src;
+  uint32_t* dst;
+  if (r0 < nh) {
+    i0 = 2u * r0; i1 = i0 + 1u; src = a_src;
+    dst = A + ((size_t)set * nb + red_off_a(k, s + 1) + r0) * PW;
+  } else {
+    const uint32_t sh = k - s - 2, r = r0 - nh, l = r >> sh, j = r & ((1u << sh) - 1u);
+    uint32_t* g = G + ((size_t)set * nb + red_off_g(k, l)) * PW;
+    const uint32_t half = 1u << (k - l - 2);
+    if (l == s) {
+      i0 = 4u * j + 1u; i1 = i0 + 2u; src = a_src;
+      dst = g + (size_t)j * PW;
+    } else {
+      i0 = 2u * j; i1 = i0 + 1u; src = g + (size_t)(((s - l - 1u) & 1u) * half) * PW;
+      dst = g + (size_t)(((s - l) & 1u) * half + j) * PW;
+    }
+  }
+  const bool from_buckets = s == 0 && src == a_src;
+  const bool e0 = from_buckets && offsets[(size_t)set * nb + i0 + 1] == offsets[(size_t)set * nb + i0];
+  const bool e1 = from_buckets && offsets[(size_t)set * nb + i1 + 1] == offsets[(size_t)set * nb + i1];
+  Proj<C> P, Q;
+  if (e0) pt_set_zero(P); else proj_load<C>(P, src + (size_t)i0 * PW);
+  if (e1) pt_set_zero(Q); else proj_load<C>(Q, src + (size_t)i1 * PW);
+  const bool zP = pt_is_zero(P), zQ = pt_is_zero(Q);
+  E x1z2, y1z2, z1z2, u, v, uu, vv, vvv, R, Aq, w;
+  F::mul(x1z2, P.X, Q.Z);
+  F::mul(y1z2, P.Y, Q.Z);
+  F::mul(z1z2, P.Z, Q.Z);
+  F::mul(w, Q.X, P.Z); F::sub(v, w, x1z2);
+  F::mul(w, Q.Y, P.Z); F::sub(u, w, y1z2);
+  const bool same = F::is_zero(u) && F::is_zero(v);
+  Proj<C> out;
+  F::sqr(uu, u);
+  F::sqr(vv, v);
+  F::mul(vvv, v, vv);
+  F::mul(R, vv, x1z2);
+  F::mul(w, uu, z1z2);
+  F::sub(Aq, w, vvv); F::sub(Aq, Aq, R); F::sub(Aq, Aq, R);
+  F::mul(out.X, v, Aq);
+  F::sub(w, R, Aq);
+  F::mul(w, u, w);
+  F::mul(R, vvv, y1z2);
+  F::sub(out.Y, w, R);
+  F::mul(out.Z, vvv, z1z2);
+  if (zP || zQ) out = zQ ? P : Q;
+  else if (same) { out = P; pt_vm<C, true>(out, Q, PC_ADD); }
+  proj_store<C>(dst, out);
+}
 // the k + 1 points the host combines, per bucket set: out[set][0] = T = A_k[0], out[set][1 + l] = G_l
 template <class C>
 __global__ void __launch_bounds__(64) k_reduce_collect(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
