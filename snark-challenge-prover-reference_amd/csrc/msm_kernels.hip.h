@@ -400,6 +400,12 @@ static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restric
 //                  stride `plane_stride` uint4s, see k_pair_level): consecutive entries of a lane then sit in adjacent 16-byte
 //                  pieces of the same sectors, and the level's stores are contiguous KiB instead of 64 partial sectors each.
 __host__ __device__ __forceinline__ size_t blk_index(uint32_t j);
+#ifndef MNT753_ACC_LINE_SPLIT
+#define MNT753_ACC_LINE_SPLIT 2   // lane-split fields of up to this many lanes per point also take the straight-line addition (measured: two-lane Fq2 -1.0 ms of 72, three-lane Fq3 neutral)
+#endif
+#ifndef MNT753_ACC_LINE
+#define MNT753_ACC_LINE 1     // base fields: straight-line mixed addition in k_bucket_accumulate instead of the VM's
+#endif
 template <class C, bool BLOCKED = false>
 __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ offsets, uint32_t n_buckets,
@@ -475,7 +481,31 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
       acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z);
       pc = PC_END;
     }
-    pt_vm<C, false>(acc, Q, pc);
+    if constexpr (((F::LANES == 1 && F::DEG == 1) || (F::LANES > 1 && F::LANES <= MNT753_ACC_LINE_SPLIT)) && MNT753_ACC_LINE) {
+      // base fields: the mixed addition in a straight line (the same eleven products as the VM's program 0..10, without its
+      // switch machine); lanes that only took over Q keep their value, equal points fall back to the VM's doubling
+      using E = typename F::E;
+      E u, v, uu, vv, vvv, R, A, w, X3, Y3;
+      F::mul(w, acc.Z, Q.X); F::sub(v, w, acc.X);
+      F::mul(w, acc.Z, Q.Y); F::sub(u, w, acc.Y);
+      const bool add = pc == PC_MADD;
+      const bool same = add && F::is_zero(u) && F::is_zero(v);
+      if constexpr (has_sqr<F>::value) { F::sqr(uu, u); F::sqr(vv, v); } else { F::mul(uu, u, u); F::mul(vv, v, v); }
+      F::mul(vvv, v, vv);
+      F::mul(R, vv, acc.X);
+      F::mul(w, uu, acc.Z);
+      F::sub(A, w, vvv); F::sub(A, A, R); F::sub(A, A, R);      // A = uu Z1 - vvv - 2R
+      F::mul(X3, v, A);
+      F::sub(w, R, A);
+      F::mul(w, u, w);
+      F::mul(R, vvv, acc.Y);
+      F::sub(Y3, w, R);
+      F::mul(w, vvv, acc.Z);
+      if (add && !same) { acc.X = X3; acc.Y = Y3; acc.Z = w; }
+      if (same) pt_vm<C, false>(acc, Q, PC_DBL);
+    } else {
+      pt_vm<C, false>(acc, Q, pc);
+    }
   }
   // last run of the segment
   if (first_run) {
@@ -1333,7 +1363,7 @@ __global__ void __launch_bounds__(256, 1) k_reduce_step_line(const uint32_t* __r
                                                             uint32_t* __restrict__ A, uint32_t* __restrict__ G, uint32_t n_sets, uint32_t k, uint32_t s) {
   using F = typename C::F;
   using E = typename F::E;
-  static_assert(F::LANES == 1 && F::DEG == 1, "base fields");
+  static_assert(F::LANES == 1 && F::DEG == 1, "base fields (the two-lane Fq2 spills in this form and measured slower than the VM)");
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t per_set = red_items(k, s);
   if (t >= n_sets * per_set) return;
@@ -1374,8 +1404,7 @@ __global__ void __launch_bounds__(256, 1) k_reduce_step_line(const uint32_t* __r
   F::mul(w, Q.Y, P.Z); F::sub(u, w, y1z2);
   const bool same = F::is_zero(u) && F::is_zero(v);
   Proj<C> out;
-  F::sqr(uu, u);
-  F::sqr(vv, v);
+  if constexpr (has_sqr<F>::value) { F::sqr(uu, u); F::sqr(vv, v); } else { F::mul(uu, u, u); F::mul(vv, v, v); }
   F::mul(vvv, v, vv);
   F::mul(R, vv, x1z2);
   F::mul(w, uu, z1z2);
