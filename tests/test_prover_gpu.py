@@ -28,6 +28,19 @@ def test_reference_proof_files(gpu, curve, flags, tmp_path):
     assert filecmp.cmp(out, expected, shallow=False)
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("env", [{"MNT753_REDUCE_PAIR": "0"}, {"MNT753_REDUCE_LINE": "0"}, {"MNT753_REDUCE_PAIR": "0", "MNT753_REDUCE_LINE": "0"},
+                                 {"MNT753_REDUCE_PAIR_MAX": "100000000"}, {"MNT753_MSM_SORT": "atomic"}])
+def test_alternative_kernel_paths_write_the_same_proof(gpu, curve, env, tmp_path):
+    """The bucket reduction has three addition kernels (the VM's, two lanes per addition, straight-line) and the sort stage two
+    variants; the environment switches between them and every combination must reproduce the reference's proof bytes."""
+    params, inp, expected = G.e2e_paths(curve)
+    out = str(tmp_path / "proof.bin")
+    r = subprocess.run([EXE, NAME[curve], "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(out, expected, shallow=False)
+
+
 @pytest.mark.parametrize("curve,log2_d", [(0, 11), (1, 10)])
 def test_synthetic_set_vs_oracle(gpu, curve, log2_d, tmp_path):
     """MNT6753 at 2^10 is the reference's `generate_parameters fast` size."""
