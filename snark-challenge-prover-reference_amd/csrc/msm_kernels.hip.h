@@ -7,17 +7,21 @@
 //
 //   k_bases_to_internal   wire affine bases -> device form (27x28-bit limbs, R'=2^756), once per base set
 //   k_precompute_windows  window table 2^(cw) P_i (affine), once per base set: every window then indexes ONE bucket set
-//   k_scalar_digits       Montgomery scalar -> integer (as_bigint), signed radix-2^c Booth digits, bucket histogram
-//   scan                  exclusive prefix sum of the histogram (bucket offsets)
-//   k_scatter             counting-sort (table row, sign) by bucket
-//   k_pair_add (x levels) batched-affine additions of adjacent entries inside every bucket, one divstep inversion per
-//                         lane batch (large sets only); k_pair_fix undoes the stand-in of cancelled pairs
+//   sort stage            Montgomery scalar -> integer (as_bigint), signed radix-2^c Booth digits, (bucket, entry) pairs; from 2^22
+//                         entries a device radix sort (msm_sort.hip), below that k_scalar_digits / scan / k_scatter (histogram
+//                         with atomics + counting sort); buckets padded to a multiple of 2^levels entries either way
+//   k_pair_level (x 3)    batched-affine additions of adjacent entries inside every bucket on a regular slot tree, operands staged
+//                         through LDS by row-cooperative LDS-DMA, one divstep inversion per lane batch (large sets only);
+//                         k_pair_fix undoes the stand-in of cancelled pairs
 //   k_bucket_accumulate   each lane sums exactly T consecutive entries (perfect SIMD balance for ANY digit
 //                         distribution); whole buckets go straight to the bucket array, the first / last partial run of
-//                         each lane goes to an edge array
+//                         each lane goes to an edge array.  Straight-line mixed additions for base fields and the two-lane
+//                         Fq2, the point VM (curve753.hip.h) otherwise
 //   k_edge_level_*        pointer-jumping sum of the edge pieces that belong to one bucket
-//   k_reduce_step         bucket reduction by halving: c - 1 launches, each one group addition deep (T and the G_l of
-//                         sum_b (b+1) B[b] = T + sum_l 2^l G_l); k_reduce_collect gathers the c points the host combines
+//   k_reduce_step*        bucket reduction by halving: c - 1 launches, each one group addition deep (T and the G_l of
+//                         sum_b (b+1) B[b] = T + sum_l 2^l G_l): _line = straight-line additions (wide steps, base fields),
+//                         _pair = two lanes per addition (narrow steps), plain = the VM; k_reduce_collect gathers the c
+//                         points the host combines
 //   k_points_to_wire      -> wire form (projective, Montgomery R=2^768)
 //   host                  only without the window table (small sets): Horner over the window sums
 // The G2 instantiations of the point kernels run on lane-split extension fields (curve753.hip.h): 2 or 3 lanes per point.
