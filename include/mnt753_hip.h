@@ -59,13 +59,19 @@ int mnt753_init(int device);
  * after initialisation, also in new threads); entry points that take a base set run on that set's device whatever the
  * current one is.  The reference shards an MSM over OpenMP threads as contiguous slices and sums the partial results
  * serially (depends/libff/libff/algebra/scalar_multiplication/multiexp.tcc:417-440); the wrapper classes do the same over
- * devices: one base set per device and slice, the scalar slices copied device 0 -> device g (mnt753_copy_peer, xGMI), one
- * projective point back per device, folded on the host in rank order with mnt753_point_add.
+ * devices: one base set per device and slice; every device streams its own slice of the witness from the input file
+ * (mnt753_load_file_to_device on that device), only the slices of coefficients_for_H travel device 0 -> device g
+ * (mnt753_copy_peer_async, xGMI); one projective point back per device, folded on the host in rank order with mnt753_point_add.
  * MNT753_SHARE_DEVICE=1 (development) maps the logical devices onto however many are visible. */
 int mnt753_init_devices(int n_devices);
 int mnt753_device_count(void);
 int mnt753_set_device(int logical_device);
 int mnt753_copy_peer(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes);
+/* The same without blocking the host: the copy is enqueued on dst_device's default stream and starts after everything enqueued so
+ * far on src_device's default stream (an event recorded there, waited for on the destination) -- how the slices of
+ * coefficients_for_H leave device 0 behind compute_H (cuda_prover_piecewise.cu:79-81) while the host goes on enqueueing.  An MSM
+ * started afterwards on dst_device with stream == NULL (mnt753_msm_start) is ordered behind the copy. */
+int mnt753_copy_peer_async(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes);
 const char* mnt753_last_error(void);
 /* number of words (uint64) of one element / point of the given kind */
 size_t mnt753_affine_words(int curve, int group);      /* 24, 48 (MNT4753 G2) or 72 (MNT6753 G2) */
@@ -167,6 +173,8 @@ int mnt753_r1cs_create(int curve, uint64_t num_inputs, uint64_t m, uint64_t nc, 
                        const uint64_t* const coeff[3], mnt753_r1cs** out);
 int mnt753_r1cs_free(mnt753_r1cs* r);
 size_t mnt753_r1cs_domain_size(const mnt753_r1cs* r);   /* nc + num_inputs + 1 */
+size_t mnt753_r1cs_num_variables(const mnt753_r1cs* r); /* m: dev_w of mnt753_r1cs_evaluate must hold m + 1 elements */
+size_t mnt753_r1cs_num_inputs(const mnt753_r1cs* r);
 int mnt753_r1cs_evaluate(mnt753_r1cs* r, const uint64_t* dev_w, uint64_t* dev_ca, uint64_t* dev_cb, uint64_t* dev_cc, size_t out_len, void* stream);
 
 /* ---- deterministic synthetic inputs (host) ---------------------------------------------------------

@@ -18,7 +18,9 @@ class Mnt753Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmnt753_hip.so")
+    """The product library next to this file; MNT753_LIB names another build of it (development A/B runs: an experimental
+    variant is loaded from where it was built instead of being copied over the product file)."""
+    return os.environ.get("MNT753_LIB") or os.path.join(_HERE, "libmnt753_hip.so")
 
 
 def lib():
@@ -37,6 +39,7 @@ def lib():
         "mnt753_device_count": (i, []),
         "mnt753_set_device": (i, [i]),
         "mnt753_copy_peer": (i, [i, vp, i, vp, sz]),
+        "mnt753_copy_peer_async": (i, [i, vp, i, vp, sz]),
         "mnt753_last_error": (C.c_char_p, []),
         "mnt753_affine_words": (sz, [i, i]),
         "mnt753_projective_words": (sz, [i, i]),
@@ -77,6 +80,8 @@ def lib():
         "mnt753_r1cs_create": (i, [i, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "mnt753_r1cs_free": (i, [vp]),
         "mnt753_r1cs_domain_size": (sz, [vp]),
+        "mnt753_r1cs_num_variables": (sz, [vp]),
+        "mnt753_r1cs_num_inputs": (sz, [vp]),
         "mnt753_r1cs_evaluate": (i, [vp, vp, vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sig.items():

@@ -27,7 +27,10 @@ struct IoStaging {
 // contract of the reference wrapper); mnt753_init_devices(n) maps logical i to physical i -- or, with MNT753_SHARE_DEVICE=1
 // (development: exercising the sharded path on a one-GPU box), to physical i % (visible devices).
 constexpr int MAX_DEVICES = 16;
-struct DevState { int phys = -1; bool ready = false; IoStaging io; };
+struct DevState {
+  int phys = -1; bool ready = false; IoStaging io;
+  hipEvent_t xfer_ev[MAX_DEVICES] = {};   // [dst]: "everything enqueued on this device's default stream so far" for a copy to dst
+};
 DevState g_devs[MAX_DEVICES];
 int g_ndev = 0;
 thread_local int t_cur_dev = 0;   // logical device the calling thread works on (mnt753_set_device)
@@ -190,6 +193,29 @@ int mnt753_copy_peer(int dst_device, void* dev_dst, int src_device, const void* 
   if (bytes && (!dev_dst || !dev_src)) return set_error(MNT753_EINVAL, "copy_peer: null");
   if (g_devs[dst_device].phys == g_devs[src_device].phys) HIP_TRY(hipMemcpy(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice));
   else HIP_TRY(hipMemcpyPeer(dev_dst, g_devs[dst_device].phys, dev_src, g_devs[src_device].phys, bytes));
+  return 0;
+}
+
+int mnt753_copy_peer_async(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes) {
+  if (dst_device < 0 || dst_device >= g_ndev || src_device < 0 || src_device >= g_ndev) return set_error(MNT753_EINVAL, "copy_peer_async: bad device");
+  if (bytes && (!dev_dst || !dev_src)) return set_error(MNT753_EINVAL, "copy_peer_async: null");
+  if (bytes == 0) return 0;
+  const int pd = g_devs[dst_device].phys, ps = g_devs[src_device].phys;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+  struct Back { int d; ~Back() { if (d >= 0) (void)hipSetDevice(d); } } back{cur};
+  if (pd == ps) {   // logical devices sharing one GPU (MNT753_SHARE_DEVICE): the default stream orders it by itself
+    HIP_TRY(hipSetDevice(pd));
+    HIP_TRY(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, nullptr));
+    return 0;
+  }
+  hipEvent_t& ev = g_devs[src_device].xfer_ev[dst_device];
+  HIP_TRY(hipSetDevice(ps));
+  if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ev, nullptr));
+  HIP_TRY(hipSetDevice(pd));
+  HIP_TRY(hipStreamWaitEvent(nullptr, ev, 0));
+  HIP_TRY(hipMemcpyPeerAsync(dev_dst, pd, dev_src, ps, bytes, nullptr));
   return 0;
 }
 

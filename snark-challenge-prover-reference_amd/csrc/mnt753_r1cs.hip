@@ -81,6 +81,7 @@ int mnt753_r1cs_create(int curve, uint64_t num_inputs, uint64_t m, uint64_t nc, 
                        const uint64_t* const coeff[3], mnt753_r1cs** out) {
   if (curve < 0 || curve > 1 || !out || !row_ptr || !col || !coeff) return set_error(MNT753_EINVAL, "r1cs_create: bad argument");
   if (int rc = require_device()) return rc;
+  if (num_inputs > m) return set_error(MNT753_EINVAL, "r1cs_create: more inputs than variables");
   for (int k = 0; k < 3; ++k) {
     if (!row_ptr[k] || row_ptr[k][0] != 0) return set_error(MNT753_EINVAL, "r1cs_create: row_ptr must start at 0");
     for (uint64_t i = 0; i < nc; ++i)
@@ -104,16 +105,24 @@ int mnt753_r1cs_create(int curve, uint64_t num_inputs, uint64_t m, uint64_t nc, 
       mnt753_r1cs_free(r);
       return set_error(MNT753_ENOMEM, "r1cs_create: device allocation failed");
     }
-    HIP_TRY(hipMemcpy(r->row_ptr[k], row_ptr[k], 8 * (nc + 1), hipMemcpyHostToDevice));
-    if (nnz) {
-      HIP_TRY(hipMemcpy(r->col[k], col[k], 4 * nnz, hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(staged, coeff[k], 96 * nnz, hipMemcpyHostToDevice));
-      const unsigned g = (unsigned)((nnz + 255) / 256);
-      if (r->frm == MOD_A) hipLaunchKernelGGL((k_coeff_to_internal<MOD_A>), dim3(g), dim3(256), 0, 0, staged, r->coeff[k], (size_t)nnz);
-      else hipLaunchKernelGGL((k_coeff_to_internal<MOD_B>), dim3(g), dim3(256), 0, 0, staged, r->coeff[k], (size_t)nnz);
-      HIP_TRY(hipDeviceSynchronize());
+    // any failure below frees the staging buffer and the partly built system before it returns
+    hipError_t e = hipMemcpy(r->row_ptr[k], row_ptr[k], 8 * (nc + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz) {
+      e = hipMemcpy(r->col[k], col[k], 4 * nnz, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(staged, coeff[k], 96 * nnz, hipMemcpyHostToDevice);
+      if (e == hipSuccess) {
+        const unsigned g = (unsigned)((nnz + 255) / 256);
+        if (r->frm == MOD_A) hipLaunchKernelGGL((k_coeff_to_internal<MOD_A>), dim3(g), dim3(256), 0, 0, staged, r->coeff[k], (size_t)nnz);
+        else hipLaunchKernelGGL((k_coeff_to_internal<MOD_B>), dim3(g), dim3(256), 0, 0, staged, r->coeff[k], (size_t)nnz);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+      }
     }
     (void)hipFree(staged);
+    if (e != hipSuccess) {
+      mnt753_r1cs_free(r);
+      return set_hip_error(e, "r1cs_create: upload / conversion", __FILE__, __LINE__);
+    }
   }
   *out = r;
   return 0;
@@ -131,6 +140,8 @@ int mnt753_r1cs_free(mnt753_r1cs* r) {
 }
 
 size_t mnt753_r1cs_domain_size(const mnt753_r1cs* r) { return r ? (size_t)(r->nc + r->num_inputs + 1) : 0; }
+size_t mnt753_r1cs_num_variables(const mnt753_r1cs* r) { return r ? (size_t)r->m : 0; }
+size_t mnt753_r1cs_num_inputs(const mnt753_r1cs* r) { return r ? (size_t)r->num_inputs : 0; }
 
 int mnt753_r1cs_evaluate(mnt753_r1cs* r, const uint64_t* dev_w, uint64_t* dev_ca, uint64_t* dev_cb, uint64_t* dev_cc, size_t out_len, void* stream) {
   if (!r || !dev_w || !dev_ca || !dev_cb || !dev_cc) return set_error(MNT753_EINVAL, "r1cs_evaluate: null argument");

@@ -48,17 +48,19 @@ extern "C" int mnt753_test_field_op(int mod, int op, const uint64_t* a, const ui
   if (mod < 0 || mod > 1 || op < 0 || op > 9 || (n && (!a || !b || !out))) return set_error(MNT753_EINVAL, "test_field_op: bad argument");
   if (int rc = require_device()) return rc;
   if (n == 0) return 0;
-  uint32_t *da = nullptr, *db = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc(&da, 96 * n));
-  HIP_TRY(hipMalloc(&db, 96 * n));
-  HIP_TRY(hipMalloc(&dout, 96 * n));
-  HIP_TRY(hipMemcpy(da, a, 96 * n, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, b, 96 * n, hipMemcpyHostToDevice));
+  struct Buf {   // freed on every path out of this function
+    uint32_t* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+  } da, db, dout;
+  HIP_TRY(hipMalloc(&da.p, 96 * n));
+  HIP_TRY(hipMalloc(&db.p, 96 * n));
+  HIP_TRY(hipMalloc(&dout.p, 96 * n));
+  HIP_TRY(hipMemcpy(da.p, a, 96 * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db.p, b, 96 * n, hipMemcpyHostToDevice));
   const unsigned g = (unsigned)((n + 63) / 64);
-  if (mod == MOD_A) hipLaunchKernelGGL((k_field_op<MOD_A>), dim3(g), dim3(64), 0, 0, op, da, db, dout, n);
-  else hipLaunchKernelGGL((k_field_op<MOD_B>), dim3(g), dim3(64), 0, 0, op, da, db, dout, n);
+  if (mod == MOD_A) hipLaunchKernelGGL((k_field_op<MOD_A>), dim3(g), dim3(64), 0, 0, op, da.p, db.p, dout.p, n);
+  else hipLaunchKernelGGL((k_field_op<MOD_B>), dim3(g), dim3(64), 0, 0, op, da.p, db.p, dout.p, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, dout, 96 * n, hipMemcpyDeviceToHost));
-  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  HIP_TRY(hipMemcpy(out, dout.p, 96 * n, hipMemcpyDeviceToHost));
   return 0;
 }

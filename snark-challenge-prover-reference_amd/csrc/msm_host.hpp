@@ -3,6 +3,7 @@
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -391,8 +392,13 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
       const size_t out_stride = blk_quads((cap / 2 + 1) * (uint64_t)V::F::LANES + 64);
 #define MNT753_PAIR_LAUNCH(FST, LST)                                                                                                         \
   do {                                                                                                                                      \
-    static bool lds_set = false;   /* the level kernels stage their operands in 145 KB of dynamic LDS per workgroup */                      \
-    if (!lds_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_level<V, FST, LST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS_BYTES)); lds_set = true; } \
+    /* the level kernels stage their operands in 145 KB of dynamic LDS per workgroup: opt in once per kernel and DEVICE */                  \
+    static std::atomic<uint32_t> lds_set{0};                                                                                                \
+    const uint32_t dev_bit = 1u << (b->device & 31);                                                                                        \
+    if (!(lds_set.load(std::memory_order_acquire) & dev_bit)) {                                                                             \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_level<V, FST, LST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS_BYTES)); \
+      lds_set.fetch_or(dev_bit, std::memory_order_release);                                                                                 \
+    }                                                                                                                                       \
     hipLaunchKernelGGL((k_pair_level<V, FST, LST>), dim3(blocks_for<typename V::F>(lanes)), dim3(256), PAIR_LDS_BYTES, st, d_aff, b->d_sorted, src_planes, \
                        src_stride, b->d_offsets, p.n_buckets, (uint32_t)(levels - l), out, b->d_sorted2, reinterpret_cast<uint4*>(out), out_stride,  \
                        reinterpret_cast<uint4*>(b->d_pair_ws), min_B, lanes, b->d_gen, b->d_fix);                              \

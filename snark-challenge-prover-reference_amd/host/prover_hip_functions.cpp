@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -53,6 +54,19 @@ struct BaseSetHolder {
   ~BaseSetHolder() { if (h) mnt753_bases_free(h); }
 };
 static int g_n_devices = 0;   // 0: not chosen yet (init_public_params reads MNT753_GPUS, default 1)
+// contiguous slice g of n elements over n_dev devices (multiexp.tcc:417-431: one = n / chunks, the last slice takes the remainder)
+static void slice_bounds(size_t n, int n_dev, int g, size_t* lo, size_t* hi) {
+  const size_t one = n / (size_t)n_dev;
+  *lo = (size_t)g * one;
+  *hi = g == n_dev - 1 ? n : (size_t)(g + 1) * one;
+}
+// elements [first, first + count) of a scalar vector, resident on one logical device (streamed there from the input file by that
+// device's own loader thread)
+struct DevSlice {
+  std::shared_ptr<DeviceBuffer> buf;
+  size_t first = 0, count = 0;
+  std::shared_ptr<Ready> ready;
+};
 // A parameter vector cut into contiguous slices, slice g resident on logical device g (multiexp.tcc:417-431: one = n / chunks,
 // the last slice takes the remainder).  One device = one slice = the single-GPU wrapper.
 struct ShardedBases {
@@ -88,6 +102,9 @@ template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
   size_t size;     // elements in the underlying buffer
   size_t offset;   // element offset honoured by multiexp / muleq / subeq (prover_reference_functions.cpp:173,254)
   std::shared_ptr<Ready> ready;   // set for vectors of a groth16_input that is still streaming in from its file
+  // several devices: ranges of the same vector that other devices hold (index = logical device, element indices of the underlying
+  // buffer); empty for vectors that only exist on device 0 (coefficients_for_H)
+  std::shared_ptr<std::vector<DevSlice>> slices;
   // device pointer; waits (once) until the loader thread has put the vector on the device
   uint64_t* ptr() const {
     if (ready) ready->wait();
@@ -132,11 +149,9 @@ public:
       read_exact(f, host.data(), host.size() * 8, path);
       auto sb = std::make_shared<ShardedBases>();
       sb->n = n;
-      const size_t one = n / (size_t)n_dev;
       for (int g = 0; g < n_dev; ++g) {
         ShardedBases::Part part;
-        part.lo = (size_t)g * one;
-        part.hi = g == n_dev - 1 ? n : (size_t)(g + 1) * one;
+        slice_bounds(n, n_dev, g, &part.lo, &part.hi);
         part.set = std::make_shared<BaseSetHolder>();
         if (n_dev > 1) check(mnt753_set_device(g), "mnt753_set_device");
         check(mnt753_bases_create(CURVE, group, host.data() + words * part.lo, 0, part.hi - part.lo, &part.set->h), "mnt753_bases_create");
@@ -167,7 +182,7 @@ public:
     FILE* f = fopen(path, "rb");
     if (!f) throw std::runtime_error(std::string("cannot open r1cs file ") + path);
     uint64_t hdr[3];
-    read_exact(f, hdr, 24, path);
+    read_exact(f, hdr, 24, path);   // read_exact closes f before it throws
     num_inputs = hdr[0]; m = hdr[1]; nc = hdr[2];
     struct stat st;
     if (stat(path, &st) != 0 || nc > ((uint64_t)1 << 31) || m > ((uint64_t)1 << 31) || (uint64_t)st.st_size < 24 + 3 * 8 * (nc + 1)) {
@@ -206,6 +221,36 @@ public:
   uint64_t r[12];
   std::thread loader;
   std::shared_ptr<double> load_seconds = std::make_shared<double>(0.0);
+  // several devices: device g > 0 streams the part of w its slices of A / B1 / B2 (w[i]) and L (w[2 + i]) multiply, from the file,
+  // on its own staging buffers and PCIe link, while device 0 reads w, ca, cb, cc -- nothing is funnelled through device 0
+  std::shared_ptr<std::vector<DevSlice>> w_slices;
+  std::vector<std::thread> slice_loaders;
+  void start_slice_loaders(const std::string& path, size_t m) {
+    const int n_dev = std::max(1, mnt753_device_count());
+    if (n_dev < 2) return;
+    w_slices = std::make_shared<std::vector<DevSlice>>((size_t)n_dev);
+    for (int g = 1; g < n_dev; ++g) {
+      size_t lo_a, hi_a, lo_l, hi_l;
+      slice_bounds(m + 1, n_dev, g, &lo_a, &hi_a);   // A, B1, B2: scalars w[lo .. hi)
+      slice_bounds(m - 1, n_dev, g, &lo_l, &hi_l);   // L: scalars w[2 + lo .. 2 + hi)  (vector_Fr_offset(w, primary_input_size + 1))
+      DevSlice& sl = (*w_slices)[(size_t)g];
+      sl.first = std::min(lo_a, lo_l + 2);
+      sl.count = std::max(hi_a, hi_l + 2) - sl.first;
+      sl.ready = std::make_shared<Ready>();
+      check(mnt753_set_device(g), "mnt753_set_device");
+      sl.buf = std::make_shared<DeviceBuffer>(96 * sl.count);
+    }
+    check(mnt753_set_device(0), "mnt753_set_device");
+    for (int g = 1; g < n_dev; ++g) {
+      DevSlice sl = (*w_slices)[(size_t)g];
+      slice_loaders.emplace_back([path, sl, g]() {
+        std::string err;
+        if (mnt753_set_device(g) != 0 || mnt753_load_file_to_device(path.c_str(), 96 * sl.first, 96 * sl.count, sl.buf->ptr) != 0)
+          err = std::string("mnt753_load_file_to_device (device ") + std::to_string(g) + "): " + mnt753_last_error();
+        sl.ready->set(err);
+      });
+    }
+  }
   groth16_input(const char* path, size_t d, size_t m) {
     FILE* f = fopen(path, "rb");
     if (!f) throw std::runtime_error(std::string("cannot open input file ") + path);
@@ -227,6 +272,7 @@ public:
     w_ready = std::make_shared<Ready>(); ca_ready = std::make_shared<Ready>(); cb_ready = std::make_shared<Ready>();
     cc_ready = std::make_shared<Ready>();
     const std::string p(path);
+    start_slice_loaders(p, m);
     struct Part { void* dst; size_t off, bytes; std::shared_ptr<Ready> ready; };
     std::vector<Part> parts = {{w->ptr, 0, 96 * n_w, w_ready}, {ca->ptr, 96 * n_w, 96 * n_c, ca_ready},
                                {cb->ptr, 96 * (n_w + n_c), 96 * n_c, cb_ready}, {cc->ptr, 96 * (n_w + 2 * n_c), 96 * n_c, cc_ready}};
@@ -250,6 +296,10 @@ public:
     if (stat(path, &st) != 0 || (unsigned long long)st.st_size != 96ull * (n_w + 1))
       throw std::runtime_error(std::string("witness file size does not match the parameters (expected ") + std::to_string(96 * (n_w + 1)) + " bytes): " + path);
     if (mnt753_r1cs_domain_size(cs->h) > n_c) throw std::runtime_error("the constraint system does not fit the parameters' evaluation domain");
+    // the evaluation kernel gathers w[col] for col <= cs.m and copies w[0 .. num_inputs]: both must stay inside the m + 1 elements of w
+    if (mnt753_r1cs_num_variables(cs->h) != m || mnt753_r1cs_num_inputs(cs->h) > m)
+      throw std::runtime_error("the constraint system has " + std::to_string(mnt753_r1cs_num_variables(cs->h)) + " variables and " +
+                               std::to_string(mnt753_r1cs_num_inputs(cs->h)) + " inputs, the parameters are for m = " + std::to_string(m));
     FILE* f = fopen(path, "rb");
     if (!f) throw std::runtime_error(std::string("cannot open witness file ") + path);
     if (fseeko(f, (off_t)(96 * n_w), SEEK_SET) != 0 || fread(r, 1, 96, f) != 96) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
@@ -261,6 +311,7 @@ public:
     w_ready = std::make_shared<Ready>(); ca_ready = std::make_shared<Ready>(); cb_ready = std::make_shared<Ready>();
     cc_ready = std::make_shared<Ready>();
     const std::string p(path);
+    start_slice_loaders(p, m);
     auto secs_out = load_seconds;
     auto w_ = w, ca_ = ca, cb_ = cb, cc_ = cc;
     auto wr = w_ready, ar = ca_ready, br = cb_ready, cr = cc_ready;
@@ -278,7 +329,10 @@ public:
       ar->set(err); br->set(err); cr->set(err);
     });
   }
-  ~groth16_input() { if (loader.joinable()) loader.join(); }
+  ~groth16_input() {
+    if (loader.joinable()) loader.join();
+    for (auto& t : slice_loaders) if (t.joinable()) t.join();
+  }
 };
 
 #define HIP_B mnt753_hip_impl<CURVE>
@@ -370,7 +424,7 @@ template <int CURVE> void HIP_B::vector_Fr_subeq(vector_Fr* a, vector_Fr* b, siz
   check(mnt753_vec_subeq(CURVE, a->ptr(), b->ptr(), size, nullptr), "mnt753_vec_subeq");
 }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_offset(vector_Fr* a, size_t offset) {
-  return new vector_Fr{a->data, a->size, offset, a->ready};
+  return new vector_Fr{a->data, a->size, offset, a->ready, a->slices};
 }
 template <int CURVE> void HIP_B::vector_Fr_copy_into(vector_Fr* src, vector_Fr* dst, size_t length) {
   // MNT4753: dst[i] = src[i] ignoring offsets (prover_reference_functions.cpp:209-212);
@@ -383,7 +437,7 @@ template <int CURVE> void HIP_B::vector_Fr_copy_into(vector_Fr* src, vector_Fr* 
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_zeros(size_t length) {
   auto b = std::make_shared<DeviceBuffer>(96 * length);
   check(mnt753_dev_memset(b->ptr, 0, 96 * length), "mnt753_dev_memset");
-  return new vector_Fr{b, length, 0, nullptr};
+  return new vector_Fr{b, length, 0, nullptr, nullptr};
 }
 
 template <int CURVE> void HIP_B::domain_iFFT(evaluation_domain* domain, vector_Fr* a) {
@@ -400,36 +454,64 @@ template <int CURVE> void HIP_B::domain_divide_by_Z_on_coset(evaluation_domain* 
 }
 template <int CURVE> size_t HIP_B::domain_get_m(evaluation_domain* domain) { return mnt753_domain_size(domain->data->h); }
 
-// sum_{i < length} scalars[i] * bases[i] over the slices of a sharded vector: slice g covers [lo_g, hi_g) of the bases, the
-// matching scalars are copied from device 0 to device g, every slice's MSM is enqueued on its own device and stream
-static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const uint64_t* scalars_dev0, size_t length, const char* what) {
+// sum_{i < length} scalars[i] * bases[i] over the slices of a sharded vector: slice g covers [lo_g, hi_g) of the bases and runs on
+// device g, on that base set's own stream.  Where the scalars come from, per device:
+//   * device 0: the vector itself (dev0(), which waits for the input loader if the vector is still streaming in);
+//   * device g > 0, the vector has a resident range there (w: DevSlice, loaded from the file by device g's own loader): that;
+//   * otherwise (coefficients_for_H, computed on device 0): an asynchronous peer copy into a grow-only staging buffer on device g,
+//     ordered behind device 0's default stream (compute_H) by an event and ahead of the MSM by the destination's default stream --
+//     the host never blocks (mnt753_copy_peer_async).
+// The slices of the other devices are enqueued first: their inputs are ready first, and device 0 is the one that waits for the file.
+struct ScalarSource {
+  std::function<const uint64_t*()> dev0;       // element `offset` of the vector on device 0
+  const std::vector<DevSlice>* slices;         // ranges of the underlying buffer on the other devices, or null
+  size_t offset;                               // element offset of the logical vector inside the underlying buffer
+};
+static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarSource& src, size_t length, const char* what) {
   auto pend = std::make_shared<PendingMsm>();
   const int n_dev = (int)sb.parts.size();
-  for (int g = 0; g < n_dev; ++g) {
-    ShardedBases::Part& part = sb.parts[g];
+  pend->sets.resize((size_t)n_dev);
+  for (int k = 0; k < n_dev; ++k) {
+    const int g = k + 1 < n_dev ? k + 1 : 0;   // 1, 2, ..., n_dev - 1, 0
+    ShardedBases::Part& part = sb.parts[(size_t)g];
     const size_t lo = part.lo, hi = std::min(part.hi, length);
     if (hi <= lo) continue;
-    const uint64_t* sc = scalars_dev0 + 12 * lo;
-    if (g > 0) {
-      if (n_dev > 1) check(mnt753_set_device(g), "mnt753_set_device");
-      if (!part.scalars || part.scalars->bytes < 96 * (hi - lo)) part.scalars = std::make_shared<DeviceBuffer>(96 * (part.hi - part.lo));
-      check(mnt753_copy_peer(g, part.scalars->ptr, 0, sc, 96 * (hi - lo)), "mnt753_copy_peer");
-      sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
+    const uint64_t* sc;
+    if (g == 0) {
+      sc = src.dev0() + 12 * lo;
+    } else {
+      const DevSlice* sl = src.slices && (size_t)g < src.slices->size() && (*src.slices)[(size_t)g].buf ? &(*src.slices)[(size_t)g] : nullptr;
+      if (sl && src.offset + lo >= sl->first && src.offset + hi <= sl->first + sl->count) {
+        sl->ready->wait();
+        sc = reinterpret_cast<const uint64_t*>(sl->buf->ptr) + 12 * (src.offset + lo - sl->first);
+      } else {
+        if (!part.scalars || part.scalars->bytes < 96 * (hi - lo)) {
+          check(mnt753_set_device(g), "mnt753_set_device");
+          part.scalars = std::make_shared<DeviceBuffer>(96 * (part.hi - part.lo));
+          check(mnt753_set_device(0), "mnt753_set_device");
+        }
+        check(mnt753_copy_peer_async(g, part.scalars->ptr, 0, src.dev0() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
+        sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
+      }
     }
     check(mnt753_msm_start(part.set->h, 0, sc, 1, hi - lo, nullptr), what);
-    pend->sets.push_back(part.set);
+    pend->sets[(size_t)g] = part.set;
   }
-  if (n_dev > 1) check(mnt753_set_device(0), "mnt753_set_device");
+  // rank order for the fold (multiexp.tcc:433-438), whatever the order of enqueueing was
+  pend->sets.erase(std::remove(pend->sets.begin(), pend->sets.end(), nullptr), pend->sets.end());
   return pend;
+}
+template <class V> static ScalarSource source_of(V* v) {
+  return ScalarSource{[v]() { return v->ptr(); }, v->slices.get(), v->offset};
 }
 template <int CURVE> typename HIP_B::G1* HIP_B::multiexp_G1(vector_Fr* scalar_start, vector_G1* g_start, size_t length) {
   G1* r = new G1();
-  r->pending = start_sharded(*g_start->data, scalar_start->ptr(), length, "mnt753_msm_start(G1)");
+  r->pending = start_sharded(*g_start->data, source_of(scalar_start), length, "mnt753_msm_start(G1)");
   return r;
 }
 template <int CURVE> typename HIP_B::G2* HIP_B::multiexp_G2(vector_Fr* scalar_start, vector_G2* g_start, size_t length) {
   G2* r = new G2();
-  r->pending = start_sharded(*g_start->data, scalar_start->ptr(), length, "mnt753_msm_start(G2)");
+  r->pending = start_sharded(*g_start->data, source_of(scalar_start), length, "mnt753_msm_start(G2)");
   return r;
 }
 
@@ -441,10 +523,10 @@ template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_witness(const ch
   return new groth16_input(path, params->d, params->m, cs->data);
 }
 template <int CURVE> void HIP_B::delete_r1cs(r1cs* a) { delete a; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_w(groth16_input* in) { return new vector_Fr{in->w, in->n_w, 0, in->w_ready}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_ca(groth16_input* in) { return new vector_Fr{in->ca, in->n_c, 0, in->ca_ready}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cb(groth16_input* in) { return new vector_Fr{in->cb, in->n_c, 0, in->cb_ready}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cc(groth16_input* in) { return new vector_Fr{in->cc, in->n_c, 0, in->cc_ready}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_w(groth16_input* in) { return new vector_Fr{in->w, in->n_w, 0, in->w_ready, in->w_slices}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_ca(groth16_input* in) { return new vector_Fr{in->ca, in->n_c, 0, in->ca_ready, nullptr}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cb(groth16_input* in) { return new vector_Fr{in->cb, in->n_c, 0, in->cb_ready, nullptr}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cc(groth16_input* in) { return new vector_Fr{in->cc, in->n_c, 0, in->cc_ready, nullptr}; }
 template <int CURVE> typename HIP_B::field* HIP_B::input_r(groth16_input* in) {
   field* f = new field();
   memcpy(f->data, in->r, 96);
@@ -465,7 +547,7 @@ template <int CURVE> static void warm_up(typename mnt753_hip_impl<CURVE>::groth1
   check(mnt753_copy_h2d(dev.ptr, host.data(), 96 * n), "mnt753_copy_h2d");
   std::vector<std::shared_ptr<PendingMsm>> pend;
   for (auto* sb : {p->B2.get(), p->A.get(), p->B1.get(), p->L.get(), p->H.get()})
-    pend.push_back(start_sharded(*sb, reinterpret_cast<const uint64_t*>(dev.ptr), sb->n, "mnt753_msm_start(warm-up)"));
+    pend.push_back(start_sharded(*sb, ScalarSource{[&dev]() { return reinterpret_cast<const uint64_t*>(dev.ptr); }, nullptr, 0}, sb->n, "mnt753_msm_start(warm-up)"));
   uint64_t sink[108];
   for (auto& pm : pend)
     for (auto& set : pm->sets) check(mnt753_msm_finish(set->h, sink), "mnt753_msm_finish(warm-up)");
@@ -513,7 +595,7 @@ template <int CURVE> typename HIP_B::vector_Fr* HIP_B::compute_H_fused(evaluatio
   const size_t m = mnt753_domain_size(domain->data->h);
   auto h = std::make_shared<DeviceBuffer>(96 * (m + 1));
   check(mnt753_compute_h(domain->data->h, ca->ptr(), cb->ptr(), cc->ptr(), reinterpret_cast<uint64_t*>(h->ptr), nullptr), "mnt753_compute_h");
-  return new vector_Fr{h, m + 1, 0, nullptr};
+  return new vector_Fr{h, m + 1, 0, nullptr, nullptr};
 }
 template <int CURVE> double HIP_B::input_load_seconds(groth16_input* in) {
   in->cc_ready->wait();
