@@ -29,8 +29,20 @@ $(LIB): $(HIP_OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# Host-only sanitizer builds (no GPU needed, GPU sanitizers do not exist on the pool): main.cpp + the wrapper over a TEST STUB of the
+# C ABI (tools/stub_abi: host memory, no arithmetic) under ASan + UBSan and under TSan.  tests/test_sanitizers_cpu.py runs them.
+SAN_SRCS := $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp tools/stub_abi/stub_mnt753.cpp
+asan: $(BUILD)/san/main_hip_asan
+tsan: $(BUILD)/san/main_hip_tsan
+$(BUILD)/san/main_hip_asan: $(SAN_SRCS) include/prover_hip_functions.hpp include/mnt753_hip.h
+	@mkdir -p $(BUILD)/san
+	g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -o $@ $(SAN_SRCS)
+$(BUILD)/san/main_hip_tsan: $(SAN_SRCS) include/prover_hip_functions.hpp include/mnt753_hip.h
+	@mkdir -p $(BUILD)/san
+	g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -o $@ $(SAN_SRCS)
+
 clean:
 	rm -rf $(BUILD) $(LIB) $(MAIN)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean asan tsan

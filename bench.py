@@ -7,15 +7,19 @@
 BASELINE.json's metric has two halves and the ONE JSON line rank 0 prints carries both:
 
   * `value` -- G1 MSM points/sec at 2^20 (MNT4753, configs[1]).  One process per GPU; a step is ONE multi-scalar
-    multiplication over the rank's 2^20 (base, scalar) pairs, bases (with their window table) and scalars resident in
-    HBM, followed -- when N > 1 -- by the only exchange the path has: an all_gather (RCCL) of one 288-byte projective point
-    per rank and the serial fold of the N partial sums (multiexp.tcc:417-440).  Per-GPU work is fixed ("weak"); the same
-    run also times the north-star split of ONE 2^20 array over the N ranks and reports it under `strong`.
+    multiplication over 2^20 (base, scalar) pairs, bases (with their window table) and scalars resident in HBM.  N > 1 is
+    the north-star split: the ONE 2^20 array is cut into N contiguous slices (multiexp.tcc:417-431), rank g runs the whole
+    Pippenger on slice g, and the only exchange the path has follows -- an all_gather (RCCL over xGMI) of one 288-byte
+    projective point per rank and the serial fold of the N partial sums (multiexp.tcc:433-438).  Total work is fixed
+    ("strong"); the same run also times 2^20 points PER GPU and reports that under `weak`.
   * `prove` -- Groth16 prove time in seconds, MNT4753, full-size parameters (configs[3]): `main_hip MNT4753 compute` (the
     C++ host over the C ABI) on the seeded synthetic files of tools/synth_files.py, timed by the prover itself with the
     reference's window ("Total time from input to output", libsnark/main.cpp:203-270) and by this script around the
     process; the sha256 of the proof is compared with the one the REFERENCE wrote for the same files
     (tests/golden/oracle_hashes.json, minted in the build container by tools/mint_oracle_hashes.py).  N = 1 only.
+  * `prove_mnt6753` -- the same for configs[4]'s curve and size (MNT6753, d = 2^15 - 1), and `cpu_prove`: the reference's own
+    `./main` (oracle/_ref/main, compiled from /root/reference by oracle/build_ref.sh) timed on this box's host cores on the same
+    files (MNT6753 2^15 always; MNT4753 at 2^17 by default and at 2^20 with BENCH_CPU_PROVE_FULL=1 -- minutes of CPU time).
 
 Secondary figures on the same line (N = 1): 2^20 FFT and compute_H (configs[2]), the G2 MSM at 2^20, the G1 MSM without
 the window table and the one-off cost of building the table, `roofline` for the dominant kernels and `cpu_baseline`.
@@ -40,7 +44,7 @@ LOG_N = 20
 ALGO_BYTES_PER_PAIR = 288          # 192 B affine G1 base + 96 B scalar, read once
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
 MODMUL_PEAK_PER_S = 22.0e9         # measured chip peak of the 753-bit Montgomery multiplier (profiles/r01/mulbench_mi355x.txt)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def sha256_file(path):
@@ -110,8 +114,28 @@ def cpu_baseline(pkg, pts, sc, np):
 
 
 # ---- full prove ----------------------------------------------------------------------------------------------
-def prove_leg(log2_d=20, curve_name="MNT4753"):
-    """main_hip on the seeded synthetic files; hash compared with the reference-minted one.
+def _run_ref_main(curve_name, pp, ip, op):
+    """The reference's own prover on this box's host cores (oracle/_ref/main = libsnark/main.cpp compiled where it lies; the
+    oracle's restatement oracle/oracle_main when that build is absent).  Returns (dict, sha256 of its output or None)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "main")
+    port = os.path.join(ROOT, "oracle", "oracle_main")
+    exe, kind = (ref, "reference") if os.access(ref, os.X_OK) else (port, "port")
+    if not os.access(exe, os.X_OK):
+        return {"error": "no CPU prover built (oracle/_ref/main, oracle/oracle_main)"}, None
+    t0 = time.time()
+    r = subprocess.run([exe, curve_name, "compute", pp, ip, op], capture_output=True, text=True)
+    wall = time.time() - t0
+    if r.returncode != 0:
+        return {"error": r.stderr[-300:], "kind": kind}, None
+    m = re.search(r"Total time from input to output:[ :]*([0-9.]+) ?(ms|s)", r.stdout)
+    secs = (float(m.group(1)) / (1e3 if m.group(2) == "ms" else 1.0)) if m else None
+    return {"kind": kind, "input_to_output_s": secs, "wall_incl_params_s": round(wall, 3), "threads": os.cpu_count(),
+            "timing_window": "libsnark/main.cpp:203-270, printed at :270"}, sha256_file(op)
+
+
+def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3):
+    """main_hip on the seeded synthetic files; hash compared with the reference-minted one (or, where no hash was minted for
+    the size, with the bytes the reference prover writes here, cpu=True).
 
     Runs in child processes BEFORE this process initialises the GPU: the metric is the reference's -- a fresh `./main` on
     an otherwise idle device.  A harness that already holds a GPU context and freed device memory measured the same prover
@@ -120,45 +144,80 @@ def prove_leg(log2_d=20, curve_name="MNT4753"):
     key = f"{curve_name}_2p{log2_d}"
     expected = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_hashes.json"))).get(key)
     work = tempfile.mkdtemp(prefix="bench_prove_", dir=os.environ.get("TMPDIR", "/tmp"))
-    pp, ip, op = (os.path.join(work, k) for k in ("params", "input", "output"))
+    pp, ip, op, oc = (os.path.join(work, k) for k in ("params", "input", "output", "output_cpu"))
     out = {"curve": curve_name, "log2_d": log2_d}
+    cpu_out = None
     try:
         t0 = time.time()
         g = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "synth_files.py"), curve_name, str(log2_d), pp, ip], capture_output=True, text=True)
         if g.returncode != 0:
             out.update(error=g.stderr[-400:], parity_ok=False)
-            return out
+            return out, cpu_out
         d = (1 << log2_d) - 1
         out.update(d=d, m=d + 1, synth_files_s=round(time.time() - t0, 2))
-        files_ok = bool(expected) and sha256_file(pp) == expected["params_sha256"] and sha256_file(ip) == expected["input_sha256"]
+        files_ok = (sha256_file(pp) == expected["params_sha256"] and sha256_file(ip) == expected["input_sha256"]) if expected else None
         t0 = time.time()
-        # three proofs of the same input in ONE process: the first is the reference's metric (fresh process, parameters loaded,
+        # `repeat` proofs of the same input in ONE process: the first is the reference's metric (fresh process, parameters loaded,
         # then input -> output); the others show what a resident prover pays per proof
-        r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", "3"], capture_output=True, text=True)
+        r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", str(repeat)], capture_output=True, text=True)
         wall = time.time() - t0
         if r.returncode != 0:
             out.update(error=r.stderr[-400:], parity_ok=False)
-            return out
+            return out, cpu_out
         m1 = re.search(r"Total time from input to output: ([0-9.]+)s", r.stdout)   # the first proof
         m2 = re.search(r"load params: ([0-9.]+)s", r.stdout)
         sha = sha256_file(op)
         out["prover_stdout_first_proof"] = [l for l in r.stdout.strip().splitlines()][:9]
         out.update(input_to_output_s=float(m1.group(1)) if m1 else None, load_params_s=float(m2.group(1)) if m2 else None,
-                   wall_incl_params_s=round(wall, 3), sha256=sha, sha256_expected=expected["output_sha256"] if expected else None,
-                   synthetic_files_match_minted=files_ok, parity_ok=bool(expected) and files_ok and sha == expected["output_sha256"],
+                   wall_incl_params_s=round(wall, 3), sha256=sha,
                    timing_window="libsnark/main.cpp:203-270 (input load + compute + output write; parameters resident)",
-                   expected_from="tests/golden/oracle_hashes.json: oracle/_ref/main (the reference, bos_coster) on the same seeded files")
-        # a second proof against resident parameters (main_hip batch mode): what a proving service pays per proof
+                   note=f"first of --repeat {repeat} in one process; B::read_params ends with one warm-up MSM per base set (parameter-load time, outside "
+                        "the window as in main.cpp:201-203): the reference's metric is a cold process, whose first proof pays page faults and code "
+                        "loading instead (0.23 s measured without the warm-up on an idle device)")
         m3 = re.findall(r"Total time from input to output: ([0-9.]+)s", r.stdout)
         if len(m3) > 1:
             out["input_to_output_s_all"] = [float(x) for x in m3]
             out["resident_proof_s"] = min(float(x) for x in m3[1:])
+        if expected:
+            out.update(sha256_expected=expected["output_sha256"], synthetic_files_match_minted=files_ok,
+                       parity_ok=bool(files_ok) and sha == expected["output_sha256"],
+                       expected_from="tests/golden/oracle_hashes.json: oracle/_ref/main (the reference, bos_coster) on the same seeded files")
+        if cpu:
+            cpu_out, cpu_sha = _run_ref_main(curve_name, pp, ip, oc)
+            cpu_out.update(curve=curve_name, log2_d=log2_d, sha256=cpu_sha, same_bytes_as_gpu=(cpu_sha == sha) if cpu_sha else None)
+            if expected and cpu_sha:
+                cpu_out["matches_minted_hash"] = cpu_sha == expected["output_sha256"]
+            if not expected:   # no minted hash for this size: the live reference run IS the parity check
+                out.update(parity_ok=bool(cpu_sha) and cpu_sha == sha, expected_from="the reference prover run by this bench on the same files (cpu_prove)")
+            if cpu_out.get("input_to_output_s") and out.get("input_to_output_s"):
+                cpu_out["gpu_input_to_output_s"] = out["input_to_output_s"]
     finally:
-        for p in (pp, ip, op):
+        for p in (pp, ip, op, oc):
             if os.path.exists(p):
                 os.remove(p)
         os.rmdir(work)
-    return out
+    return out, cpu_out
+
+
+def prove_legs():
+    """All the prove legs of the bench line, before this process touches the GPU."""
+    legs = {}
+    legs["prove"], _ = prove_leg(20, "MNT4753")
+    want_cpu = os.environ.get("BENCH_CPU_PROVE", "1") != "0"
+    legs["prove_mnt6753"], cpu6 = prove_leg(15, "MNT6753", cpu=want_cpu)
+    cpu = []
+    if cpu6:
+        cpu.append(cpu6)
+    if want_cpu:
+        # MNT4753: 2^20 takes minutes on any host (401-551 s on 8 cores, BASELINE.md section 2), so by default the CPU prover runs
+        # the 2^17 files (no minted hash at that size: its bytes are compared with main_hip's directly)
+        log2 = 20 if os.environ.get("BENCH_CPU_PROVE_FULL") == "1" else 17
+        gpu4, cpu4 = prove_leg(log2, "MNT4753", cpu=True, repeat=1)
+        if cpu4:
+            cpu4["gpu_parity_ok"] = gpu4.get("parity_ok")
+            cpu.append(cpu4)
+    legs["cpu_prove"] = cpu
+    return legs
 
 
 def main():
@@ -182,9 +241,9 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     # the full-prove leg first, in child processes, while this process has not touched the GPU yet (see prove_leg)
-    prove = None
+    legs = None
     if world == 1 and not args.no_prove and args.log_n == LOG_N:
-        prove = prove_leg()
+        legs = prove_legs()
 
     import numpy as np
     import torch
@@ -208,21 +267,10 @@ def main():
     pkg.init(dev_index)
 
     n = 1 << args.log_n
-    # rank g owns slice g of an (world * n)-point MSM: distinct seeds per rank
-    pts = pkg.synth_points(0, 1, 42 + 1000 * rank, n)
-    sc = pkg.synth_scalars(0, 43 + 1000 * rank, n)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    bases = pkg.BaseSet(0, 1, pts)                                  # parameters: resident before timing (main.cpp:201-203)
-    torch.cuda.synchronize()
-    precompute_ms = (time.perf_counter() - t0) * 1e3
-    d_sc = torch.from_numpy(sc.view(np.int64)).to(device)          # scalars resident in HBM
+    if world > 1 and not share:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus, "bench.py --gpus N runs N ranks over RCCL"
     stream = torch.cuda.current_stream().cuda_stream
     comm_dev = None if share else device
-
-    def step():
-        local = bases.msm(d_sc.data_ptr(), n=n, on_device=True, stream=stream)
-        return pkg.parallel.msm_sharded(pkg.api, 0, 1, local, comm_dev)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -245,54 +293,70 @@ def main():
             elapsed = float(t.item())
         return res, elapsed, phases
 
+    # The benchmark input: ONE array of 2^log_n (base, scalar) pairs (seeds 42 / 43).  N = 1: this rank owns all of it.  N > 1, the
+    # headline: rank g owns the contiguous slice g of it (multiexp.tcc:417-431), resident with its window table before timing.
+    lo, hi = pkg.parallel.shard_range(n, rank, world)
+    pts = pkg.synth_points(0, 1, 42, n)
+    sc = pkg.synth_scalars(0, 43, n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bases = pkg.BaseSet(0, 1, pts[lo:hi])                           # parameters: resident before timing (main.cpp:201-203)
+    torch.cuda.synchronize()
+    precompute_ms = (time.perf_counter() - t0) * 1e3
+    d_sc = torch.from_numpy(sc[lo:hi].copy().view(np.int64)).to(device)   # scalars resident in HBM
+
+    def step():
+        local = bases.msm(d_sc.data_ptr(), n=hi - lo, on_device=True, stream=stream)
+        return pkg.parallel.msm_sharded(pkg.api, 0, 1, local, comm_dev)
+
     out, elapsed, tot_ms = timed(step, args.steps, args.warmup)
     acc_ms = [t["accumulate_ms"] for t in tot_ms]
     plan = pkg.msm_last_plan()
-
-    # parity of what was just timed: every rank's slice through its discrete logs, folded like the timed path
-    exp_local = pkg.synth_expected_msm(0, 1, 42 + 1000 * rank, sc)
-    exp = pkg.parallel.msm_sharded(pkg.api, 0, 1, exp_local, comm_dev)
+    # parity of what was just timed: the whole array through its discrete logs (one host scalar multiplication)
+    exp = pkg.synth_expected_msm(0, 1, 42, sc)
     ok = bool(np.array_equal(pkg.point_to_affine(0, 1, out), pkg.point_to_affine(0, 1, exp)))
 
-    # strong scaling, the north-star split: ONE 2^log_n array (rank 0's), contiguous slice per rank (multiexp.tcc:417-431)
-    strong = None
+    # weak scaling beside it (N > 1): 2^log_n points PER GPU, rank g with its own array, same exchange and fold
+    weak = None
     if world > 1:
-        lo, hi = pkg.parallel.shard_range(n, rank, world)
-        pts0 = pts if rank == 0 else pkg.synth_points(0, 1, 42, n)
-        sc0 = sc if rank == 0 else pkg.synth_scalars(0, 43, n)
-        sl = pkg.BaseSet(0, 1, pts0[lo:hi])
-        d_sl = torch.from_numpy(sc0[lo:hi].copy().view(np.int64)).to(device)
+        bases.close()
+        pts_w = pkg.synth_points(0, 1, 42 + 1000 * rank, n) if rank else pts
+        sc_w = pkg.synth_scalars(0, 43 + 1000 * rank, n) if rank else sc
+        bw = pkg.BaseSet(0, 1, pts_w)
+        d_w = torch.from_numpy(sc_w.view(np.int64)).to(device)
 
-        def step_strong():
-            local = sl.msm(d_sl.data_ptr(), n=hi - lo, on_device=True, stream=stream)
+        def step_weak():
+            local = bw.msm(d_w.data_ptr(), n=n, on_device=True, stream=stream)
             return pkg.parallel.msm_sharded(pkg.api, 0, 1, local, comm_dev)
 
-        s_out, s_elapsed, _ = timed(step_strong, args.steps, args.warmup)
-        s_ok = bool(np.array_equal(pkg.point_to_affine(0, 1, s_out), pkg.point_to_affine(0, 1, pkg.synth_expected_msm(0, 1, 42, sc0))))
-        strong = {"scaling": "strong", "workload": f"one 2^{args.log_n} MNT4753 G1 MSM split into {world} contiguous slices", "value": n * args.steps / s_elapsed,
-                  "unit": "points/s", "ms_per_step": s_elapsed / args.steps * 1e3, "parity_ok": s_ok}
-        ok = ok and s_ok
-        sl.close()
+        w_out, w_elapsed, _ = timed(step_weak, args.steps, args.warmup)
+        w_exp = pkg.parallel.msm_sharded(pkg.api, 0, 1, pkg.synth_expected_msm(0, 1, 42 + 1000 * rank, sc_w), comm_dev)
+        w_ok = bool(np.array_equal(pkg.point_to_affine(0, 1, w_out), pkg.point_to_affine(0, 1, w_exp)))
+        weak = {"scaling": "weak", "workload": f"2^{args.log_n} MNT4753 G1 points per GPU, {world} GPUs, one all_gather + fold per MSM",
+                "value": world * n * args.steps / w_elapsed, "unit": "points/s", "ms_per_step": w_elapsed / args.steps * 1e3, "parity_ok": w_ok}
+        ok = ok and w_ok
+        bw.close(); del d_w
 
     line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * n * args.steps / elapsed
+        value = n * args.steps / elapsed
         acc = float(np.mean(acc_ms))
-        achieved = ALGO_BYTES_PER_PAIR * n / (acc * 1e-3) / 1e9
+        n_local = hi - lo                       # pairs one launch of the dominant kernels processes on this rank
+        achieved = ALGO_BYTES_PER_PAIR * n_local / (acc * 1e-3) / 1e9
         plan_c, windows = plan["window_bits"], plan["windows"]
         levels = plan.get("pair_levels", 0)
         # Montgomery products per sorted entry: an affine pair addition is 5 products + 1 squaring (0.76 of a product) including
         # the 3 of the simultaneous inversion, on 1/2, 1/4, ... of the entries; one divstep inversion (~94 products) per lane and
         # level over B = slots / 65536 lanes (at least 48); 11 per mixed addition on what is left
-        slots = [windows * n / 2 ** l for l in range(1, levels + 1)]
-        prod_per_entry = sum((5.76 + 94.0 / max(48.0, sl / 65536.0)) / 2 ** l for l, sl in zip(range(1, levels + 1), slots)) + 11.0 / 2 ** levels
+        slots = [windows * n_local / 2 ** l for l in range(1, levels + 1)]
+        prod_per_entry = sum((5.76 + 94.0 / max(8.0, sl / 65536.0)) / 2 ** l for l, sl in zip(range(1, levels + 1), slots)) + 11.0 / 2 ** levels
         kernel_name = "k_bucket_accumulate<Mnt4G1>" if levels == 0 else f"k_pair_level<Mnt4G1> x{levels} + k_bucket_accumulate<Mnt4G1>"
         # PMC traffic of the same phase (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh); quoted only
         # while the kernel sources are the ones it was measured on
         traffic, traffic_info = None, None
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "accumulate_traffic.json")
-        if os.path.exists(tpath) and args.log_n == LOG_N:
+        if os.path.exists(tpath) and args.log_n == LOG_N and world == 1:
             tj = json.load(open(tpath))
             if tj.get("kernels_fingerprint") == kernels_fingerprint():
                 traffic = tj.get("hbm_bytes_per_launch")
@@ -310,30 +374,31 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "parity_ok": ok,
-            "config": {"workload": f"MNT4753 G1 Pippenger MSM, 2^{args.log_n} bases per GPU, bit-exact vs libff::multi_exp",
-                       "curve": "MNT4753", "group": "G1", "points_per_gpu": n, "window_bits": plan_c, "windows": windows,
+            "config": {"workload": f"MNT4753 G1 Pippenger MSM, 2^{args.log_n} bases" + (f" split into {world} contiguous slices (one per GPU)" if world > 1 else "") +
+                                   ", bit-exact vs libff::multi_exp",
+                       "curve": "MNT4753", "group": "G1", "points": n, "points_per_gpu": n_local, "window_bits": plan_c, "windows": windows,
                        "window_table": plan["window_table"],
-                       "parallelism": f"slice-per-gpu x{world}, all_gather of one projective point per rank"},
+                       "parallelism": f"slice-per-gpu x{world}, all_gather (RCCL) of one projective point per rank, serial fold (multiexp.tcc:417-440)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_info": traffic_info, "kernel": kernel_name, "kernel_ms": acc,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PAIR * n,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PAIR * n_local,
                          "note": "bucket accumulation phase of one MSM (HIP events on the launch stream). `achieved` is ALGORITHMIC bytes / time as the "
                                  "contract asks; the phase is bound by the 753-bit multiplier (modmul_frac) and, in the first pairing level, by scattered "
                                  "table-row gathers (traffic_info.frac_of_hbm_peak), not by streaming",
                          "pair_levels": levels, "products_per_entry": prod_per_entry,
-                         "modmul_per_s": prod_per_entry * windows * n / (acc * 1e-3), "modmul_peak_per_s": MODMUL_PEAK_PER_S,
-                         "modmul_frac": prod_per_entry * windows * n / (acc * 1e-3) / MODMUL_PEAK_PER_S,
-                         "mixed_addition_equivalents_per_s": windows * n / (acc * 1e-3)},
+                         "modmul_per_s": prod_per_entry * windows * n_local / (acc * 1e-3), "modmul_peak_per_s": MODMUL_PEAK_PER_S,
+                         "modmul_frac": prod_per_entry * windows * n_local / (acc * 1e-3) / MODMUL_PEAK_PER_S,
+                         "mixed_addition_equivalents_per_s": windows * n_local / (acc * 1e-3)},
             "phases_ms": {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},
             "precompute_ms": precompute_ms,
         }
-        if strong:
-            line["strong"] = strong
+        if weak:
+            line["weak"] = weak
 
     if world == 1:
         if not args.no_cpu_baseline:
@@ -373,6 +438,45 @@ def main():
             extras["fft_2p20_algorithmic_GBps"] = 192.0 * m / (extras["fft_2p20_ms"] * 1e-3) / 1e9
             extras["compute_h_2p20_ms"] = ev_time(lambda: dom.compute_h(vecs[0].data_ptr(), vecs[1].data_ptr(), vecs[2].data_ptr(), dh.data_ptr(), stream=stream), 5)
             dom.close(); del vecs, dh
+            # BASELINE configs[2] as a roofline object of its own (192 B per element per transform = 96 B read +
+            # 96 B written once).  One transform = three launches of k_ntt_group (8 + 8 + 4 butterfly stages on LDS tiles), i.e. three
+            # passes over HBM: 604 MB moved for 201 MB algorithmic; (m / 2) log2 m = 10.5 M butterflies, one product each.
+            fft_s = extras["fft_2p20_ms"] * 1e-3
+            line["roofline_fft"] = {"bound": "hbm", "achieved": 192.0 * m / fft_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": 192.0 * m / fft_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                                    "kernel": "k_ntt_group x3 (one 2^20 FFT over Fr of MNT4753; HIP events on the launch stream)", "kernel_ms": extras["fft_2p20_ms"],
+                                    "algorithmic_bytes_per_launch": 192 * m, "passes_over_hbm": 3, "moved_bytes_by_design": 3 * 192 * m,
+                                    "moved_frac_of_hbm_peak": 3 * 192.0 * m / fft_s / 1e9 / HBM_PEAK_GBPS,
+                                    "butterfly_products": (m // 2) * 20, "modmul_per_s": (m // 2) * 20 / fft_s,
+                                    "modmul_frac": (m // 2) * 20 / fft_s / MODMUL_PEAK_PER_S,
+                                    "compute_h_ms": extras["compute_h_2p20_ms"],
+                                    "compute_h_algorithmic_GBps": 4 * 96.0 * m / (extras["compute_h_2p20_ms"] * 1e-3) / 1e9,
+                                    "note": "bound by the 753-bit multiplier inside the LDS passes, not by HBM (basic_radix2_domain_aux.tcc:167-202 is the transform)"}
+            # The witness-map front end at circuit scale (the first loop of r1cs_to_qap_witness_map,
+            # r1cs_to_qap.tcc:223-237): 2^20 - 8 constraints, three matrices, 3 terms per row on average.  HBM-bound by design: per
+            # term 96 B of the assignment gathered + 112 B coefficient + 4 B index, per row 96 B written + 16 B of row pointers.
+            try:
+                rng = np.random.default_rng(1)
+                ncs, mv = m - 8, m - 1
+                pool = pkg.synth_scalars(0, 901, 1024)
+                mats = []
+                for k in range(3):
+                    cnt = rng.integers(1, 6, size=ncs)
+                    rp = np.zeros(ncs + 1, dtype=np.uint64); rp[1:] = np.cumsum(cnt)
+                    nnz = int(rp[ncs])
+                    mats.append((rp, rng.integers(0, mv + 1, size=nnz).astype(np.uint32), pool[rng.integers(0, 1024, size=nnz)]))
+                cs = pkg.R1cs(0, 5, mv, ncs, mats)
+                terms = sum(int(t[0][ncs]) for t in mats)
+                wv = torch.from_numpy(pkg.synth_scalars(0, 77, m).view(np.int64)).to(device)
+                abc = [torch.empty(m * 12, dtype=torch.int64, device=device) for _ in range(3)]
+                r1_ms = ev_time(lambda: cs.evaluate(wv.data_ptr(), abc[0].data_ptr(), abc[1].data_ptr(), abc[2].data_ptr(), m, stream=stream), 10)
+                r1_bytes = terms * (96 + 112 + 4) + 3 * m * (96 + 16)
+                extras["r1cs_evaluate_2p20"] = {"ms": r1_ms, "terms": terms, "rows": 3 * ncs, "bytes_by_design": r1_bytes,
+                                                "GBps": r1_bytes / (r1_ms * 1e-3) / 1e9, "frac_of_hbm_peak": r1_bytes / (r1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                "products_per_s": terms / (r1_ms * 1e-3)}
+                cs.close(); del wv, abc, mats
+            except Exception as ex:   # the front end is a "next" row of the scope table: its timing must not take the bench line down
+                extras["r1cs_evaluate_2p20"] = {"error": repr(ex)[:200]}
             # G2 MSM at 2^20 (Fq2): 480 B algorithmic per pair
             g2 = pkg.synth_points(0, 2, 52, n)
             b2 = pkg.BaseSet(0, 2, g2)
@@ -381,15 +485,63 @@ def main():
             extras["g2_msm_points_per_s"] = n * 3 / e3
             extras["g2_parity_ok"] = bool(np.array_equal(pkg.point_to_affine(0, 2, r2), pkg.point_to_affine(0, 2, pkg.synth_expected_msm(0, 2, 52, sc))))
             ok = ok and extras["g2_parity_ok"]
+            # The sizes an N-way split of the benchmark configurations produces (multiexp.tcc:417-431 on N devices), on ONE GPU: what
+            # the first multi-GPU run should be held against.  Prefixes of the benchmark arrays (the generators are index-wise),
+            # each checked through its discrete logs.
+            def msm_ms(curve, group, seed_p, seed_s, pts_a, sc_a):
+                k = len(pts_a)
+                bs = pkg.BaseSet(curve, group, pts_a)
+                d = torch.from_numpy(sc_a.copy().view(np.int64)).to(device)
+                best = None
+                for rep in range(3):
+                    res = bs.msm(d.data_ptr(), n=k, on_device=True, stream=stream)
+                    t = pkg.msm_last_timing()["total_ms"]
+                    best = t if rep and (best is None or t < best) else (best if rep else None)
+                good = bool(np.array_equal(pkg.point_to_affine(curve, group, res), pkg.point_to_affine(curve, group, pkg.synth_expected_msm(curve, group, seed_p, sc_a))))
+                lv = pkg.msm_last_plan()["pair_levels"]
+                bs.close(); del d
+                return best, lv, good
+            sweep, sweep_ok = {}, True
+            for shift in (0, 1, 2, 3):
+                k = n >> shift
+                for group, arr, seed_p in ((1, pts, 42), (2, g2, 52)):
+                    t, lv, good = msm_ms(0, group, seed_p, 43, arr[:k], sc[:k])
+                    sweep[f"MNT4753_G{group}_2p{args.log_n - shift}"] = {"ms": round(t, 3), "pair_levels": lv}
+                    sweep_ok = sweep_ok and good
+            n6 = 1 << 15
+            p61, p62, s6 = pkg.synth_points(1, 1, 42, n6), pkg.synth_points(1, 2, 52, n6), pkg.synth_scalars(1, 43, n6)
+            for shift in (0, 1, 2, 3):
+                k = n6 >> shift
+                for group, arr, seed_p in ((1, p61, 42), (2, p62, 52)):
+                    t, lv, good = msm_ms(1, group, seed_p, 43, arr[:k], s6[:k])
+                    sweep[f"MNT6753_G{group}_2p{15 - shift}"] = {"ms": round(t, 3), "pair_levels": lv}
+                    sweep_ok = sweep_ok and good
+            # predicted prove time on N devices: the G2 MSM and the four G1 MSMs of a slice back to back on its device (the point
+            # kernels own the whole chip: concurrency only fills launch gaps), compute_H on device 0 ahead of the H
+            # slices, the O(1) host tail; MNT6753 with its own compute_H share (2^15: 0.3 ms)
+            pred = {}
+            for N, shift in ((1, 0), (2, 1), (4, 2), (8, 3)):
+                g1 = sweep[f"MNT4753_G1_2p{args.log_n - shift}"]["ms"]; gg2 = sweep[f"MNT4753_G2_2p{args.log_n - shift}"]["ms"]
+                pred[f"MNT4753_2p20_{N}gpu_s"] = round((gg2 + 4 * g1 + extras["compute_h_2p20_ms"] + 2.5) * 1e-3, 4)
+                h1 = sweep[f"MNT6753_G1_2p{15 - shift}"]["ms"]; h2 = sweep[f"MNT6753_G2_2p{15 - shift}"]["ms"]
+                pred[f"MNT6753_2p15_{N}gpu_s"] = round((h2 + 4 * h1 + 0.3 + 2.5) * 1e-3, 4)
+            extras["slice_sweep_ms"] = sweep
+            extras["slice_sweep_parity_ok"] = sweep_ok
+            extras["predicted_prove_s"] = dict(pred, model="G2 + 4 x G1 MSM of one slice + compute_H (device 0) + 2.5 ms host tail and launch gaps; measured on ONE GPU at the "
+                                                     "slice sizes -- multi-GPU hardware was not available to the builder")
+            ok = ok and sweep_ok
             b2.close(); del g2
             line["extras"] = extras
         else:
             bases.close()
         del d_sc
         torch.cuda.empty_cache()
-        if prove is not None:
-            line["prove"] = prove
-            ok = ok and bool(prove.get("parity_ok"))
+        if legs is not None:
+            line.update(legs)
+            ok = ok and bool(legs["prove"].get("parity_ok")) and bool(legs["prove_mnt6753"].get("parity_ok"))
+            for c in legs["cpu_prove"]:
+                if c.get("same_bytes_as_gpu") is False:
+                    ok = False
         line["parity_ok"] = ok
     if rank == 0:
         print(json.dumps(line), flush=True)

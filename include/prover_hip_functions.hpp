@@ -87,6 +87,7 @@ public:
 
   static void delete_G1(G1 *a);
   static void delete_G2(G2 *a);
+  static void delete_field(field *a);   // extension: the reference never frees the B::field of input_r (no such member there)
   static void delete_vector_Fr(vector_Fr *a);
   static void delete_vector_G1(vector_G1 *a);
   static void delete_vector_G2(vector_G2 *a);

@@ -29,6 +29,14 @@ struct FieldFp {
   static constexpr bool HAS_SQR = true;
   static HD void mul(E& r, const E& a, const E& b) { fp_mul(r, a, b); }
   static HD void sqr(E& r, const E& a) { fp_sqr(r, a); }
+  // lazy arithmetic of the pairing levels (fp753.hip.h): signed limb-wise differences into a signed-product multiplier
+  static constexpr bool HAS_LAZY = true;
+  static HD void mul_s(E& r, const E& a, const E& b) { fp_mul_s(r, a, b); }
+  static HD void sqr_s(E& r, const E& a) { fp_sqr_s(r, a); }
+  static HD void sub_raw(E& r, const E& a, const E& b) { fp_sub_raw(r, a, b); }
+  static HD void addsub_raw(E& r, const E& a, const E& y, bool subtract) { fp_addsub_raw(r, a, y, subtract); }
+  static HD void norm(E& r, const E& a) { fp_norm(r, a); }
+  static HD bool raw_maybe_zero(const E& d) { return fp_raw_maybe_zero(d); }
   static HD void inv(E& r, const E& a) { fp_inv(r, a); }
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
@@ -380,6 +388,8 @@ template <> struct SplitOf<Mnt6G2> { using type = Mnt6G2S; };
 
 template <class F, class = void> struct has_sqr : std::false_type {};
 template <class F> struct has_sqr<F, std::enable_if_t<F::HAS_SQR>> : std::true_type {};
+template <class F, class = void> struct has_lazy : std::false_type {};
+template <class F> struct has_lazy<F, std::enable_if_t<F::HAS_LAZY>> : std::true_type {};
 
 template <class C>
 struct Proj {

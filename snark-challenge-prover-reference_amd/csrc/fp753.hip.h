@@ -20,6 +20,7 @@
 // development; the product only ever runs it on the GPU.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "mnt753_constants.h"
 
 #if defined(__HIPCC__)
@@ -35,11 +36,118 @@ struct Fp {
   uint32_t l[NL];
 };
 
+// ---- Montgomery product: one level of subtractive Karatsuba on the product half --------------------------------------------
+// a = a0 + a1 B, b = b0 + b1 B with B = 2^(14 * 28) (14 + 13 limbs):
+//     a b = a0 b0 + [(a0 - a1)(b1 - b0) + a0 b0 + a1 b1] B + a1 b1 B^2
+// 196 + 169 + 196 = 561 multiply-adds instead of 729 (the middle product has signed factors: v_mad_i64_i32); the Montgomery
+// reduction half (729) is unchanged.  Column k of the product is assembled on the fly from three fresh column sums --
+//     lo_k = (a0 b0)_k,   hi_(k-14) = (a1 b1)_(k-14),   md_(k-14) = ((a0 - a1)(b1 - b0))_(k-14)
+// plus F[k] = lo_(k-14) + hi_(k-28), a 14-entry window of 64-bit sums that every lo / hi column feeds once more 14 columns later.
+// All sums are exact modulo 2^64 and the assembled column equals the schoolbook column, so the bounds of the schoolbook product
+// hold unchanged (27 |a_i| |b_j| + 27 2^56 < 2^63 for signed limbs).  Measured on MI355X (tools/experiments/mul_variants.hip,
+// profiles/r03/mul_variants_mi355x.txt): 21.4 G products/s at one wave per SIMD against 18.7 for the schoolbook product scanning
+// (+14 %; at one wave a multiply-add issues every ~5.9 cycles, an add every 4, and the column sums no longer hang on the carry of
+// the reduction), 23.7 against 22.5 at four waves.  In the product's kernels that gain does NOT arrive (same-box A/B, round 3,
+// profiles/r03/ab_karatsuba.txt): the 14-entry window and the operand differences cost ~56 more live registers in kernels that
+// already park 200+ values in AGPRs -- G1 accumulation phase 22.8 -> 22.4 ms, bucket reduction 2.04 -> 2.25 ms (k_reduce_step_line
+// starts to spill), i.e. nothing; the fused two- / three-product multipliers of the lane-split fields spill 1-2 KB per lane with it
+// and the G2 MSM ran 18x slower.  So the schoolbook product scanning stays the default and this stays a build option for the single
+// product (-DMNT753_KARATSUBA=1), kept correct by tools/host_fp_check.cpp.
+#ifndef MNT753_KARATSUBA
+#define MNT753_KARATSUBA 0
+#endif
+constexpr int KH = 14, KL = NL - KH;   // limbs of the low / high half
+// AL / BL: limb types of the operands as the multiply-add sees them (uint32_t: v_mad_u64_u32, int32_t: v_mad_i64_i32).
+// N products are summed under ONE reduction (the fused multipliers of the lane-split extension fields: N = 2, 3).
+template <int M, int N, class AL, class BL>
+HD void fp_mulN_karatsuba(uint32_t (&r)[NL], const AL* const (&a)[N], const BL* const (&b)[N]) {
+  typedef typename std::conditional<std::is_signed<AL>::value || std::is_signed<BL>::value, int64_t, uint64_t>::type P;   // product type of lo / hi
+  int32_t da[N][KH], db[N][KH];
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+#pragma unroll
+    for (int i = 0; i < KH; ++i) {
+      da[p][i] = (int32_t)a[p][i] - (i < KL ? (int32_t)a[p][KH + i] : 0);
+      db[p][i] = (i < KL ? (int32_t)b[p][KH + i] : 0) - (int32_t)b[p][i];
+    }
+  }
+  int64_t F[KH];
+#pragma unroll
+  for (int i = 0; i < KH; ++i) F[i] = 0;
+  int64_t carry = 0;
+  uint32_t m[NL];
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; ++k) {
+    int64_t t = carry + F[k % KH];
+    int64_t fut = 0;
+    if (k < 2 * KH - 1) {                        // lo_k
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        P s = 0;
+#pragma unroll
+        for (int i = (k < KH ? 0 : k - KH + 1); i <= (k < KH ? k : KH - 1); ++i) s += (P)a[p][i] * (P)b[p][k - i];
+        t += (int64_t)s; fut += (int64_t)s;
+      }
+    }
+    if (k >= KH && k - KH < 2 * KH - 1) {        // md_(k-14)
+      const int q = k - KH;
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        int64_t s = 0;
+#pragma unroll
+        for (int i = (q < KH ? 0 : q - KH + 1); i <= (q < KH ? q : KH - 1); ++i) s += (int64_t)da[p][i] * db[p][q - i];
+        t += s;
+      }
+    }
+    if (k >= KH && k - KH < 2 * KL - 1) {        // hi_(k-14)
+      const int q = k - KH;
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        P s = 0;
+#pragma unroll
+        for (int i = (q < KL ? 0 : q - KL + 1); i <= (q < KL ? q : KL - 1); ++i) s += (P)a[p][KH + i] * (P)b[p][KH + q - i];
+        t += (int64_t)s; fut += (int64_t)s;
+      }
+    }
+    F[k % KH] = fut;                             // lo_k + hi_(k-14): added again at column k + 14
+    uint64_t mp = 0;
+    if (k < NL) {
+#pragma unroll
+      for (int i = 0; i < k; ++i) mp += (uint64_t)m[i] * FPC[M].p[k - i];
+      t += (int64_t)mp;
+      m[k] = ((uint32_t)t * FPC[M].inv) & LMASK;
+      t += (int64_t)((uint64_t)m[k] * FPC[M].p[0]);
+    } else {
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; ++i) mp += (uint64_t)m[i] * FPC[M].p[k - i];
+      t += (int64_t)mp;
+      r[k - NL] = (uint32_t)t & LMASK;
+    }
+    carry = t >> LB;
+  }
+  r[NL - 1] = (uint32_t)carry;
+}
+template <int M, class AL, class BL>
+HD void fp_mul_karatsuba(uint32_t (&r)[NL], const AL (&a)[NL], const BL (&b)[NL]) {
+  const AL* const pa[1] = {a};
+  const BL* const pb[1] = {b};
+  fp_mulN_karatsuba<M, 1>(r, pa, pb);
+}
+
 // ---- Montgomery product, radix 2^756, two interleaved column accumulators ------------------
 // r = a*b*2^-756 mod p, r < 2p provided a*b < 4p^2 (e.g. a,b < 2p; or a < 4p, b < p).
 // Limbs of a may be up to 2^29 (one un-normalised addition) -- the column bound still holds.
 template <int M>
 HD void fp_mul(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
+#if MNT753_KARATSUBA
+  {
+    uint32_t out[NL];                    // (r may alias an operand)
+    fp_mul_karatsuba<M>(out, a.l, b.l);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = out[i];
+    return;
+  }
+#endif
   uint64_t acc = 0, acc2 = 0;
   uint32_t m[NL];
 #pragma unroll
@@ -232,6 +340,136 @@ HD void fp_sub(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
     c = t >> LB;
   }
   fp_reduce2p<M>(r, s);
+}
+
+// ---- lazy arithmetic for the batched-affine pairing levels (msm_kernels.hip.h, k_pair_level) ------------------------------
+// A subtraction with carries and a conditional correction (fp_sub) is 270 VALU instructions, a sixth of a product, and an affine
+// addition needs seven of them.  The 28-bit limbs leave four spare bits per word, so differences are taken LIMB-WISE with no
+// carry at all (27 instructions; limbs become signed, |limb| < 2^29 after one addition / subtraction of 28-bit operands) and fed
+// straight into a multiplier whose product half uses the signed multiply-add (v_mad_i64_i32, same rate as v_mad_u64_u32):
+//   * fp_mul_s / fp_sqr_s: operands with int32 limbs, 27 |a_i| |b_j| + 27 2^56 < 2^63 (e.g. 2^29 x 2^28 or 2^30 x 2^28); the
+//     Montgomery reduction is unchanged (m_k from the low 28 bits of the two's-complement column, arithmetic shifts).  Result:
+//     limbs 0..25 in [0, 2^28), limb 26 SIGNED, value in (-|a b| / R', |a b| / R' + p).
+//   * fp_norm: signed un-normalised limbs (|limb| < 2^30, |value| < 5p) -> limbs in [0, 2^28), value in [0.49p, 1.51p), a subset
+//     of the lazy range [0, 2p) of everything else in this file: the quotient comes from the top limb alone (the lower limbs
+//     move it by < 2^-20 p), one pass subtracts q p and carries -- 4 instructions per limb, and only the two coordinates an
+//     addition hands on need it.
+// Values mod p are unchanged by all of it, so results are bit-exact against the eager formulas (tools/host_fp_check.cpp).
+// A limb as an int32 the compiler knows nothing about.  Where LLVM can prove one operand non-negative (a masked limb) it turns
+// sext x sext into sext x zext and expands THAT into two unsigned multiply-adds and two moves per product (hipcc 7.2: the signed
+// multiplier came out at 3700 instructions instead of 1650); behind an empty asm every product is one v_mad_i64_i32.
+HD int32_t fp_opaque_limb(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(v));
+#endif
+  return (int32_t)v;
+}
+template <int M>
+HD void fp_mul_s(Fp<M>& r, const Fp<M>& a_in, const Fp<M>& b_in) {
+  int64_t acc = 0;
+  uint64_t acc2 = 0;
+  uint32_t m[NL];
+  struct { int32_t l[NL]; } a, b;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { a.l[i] = fp_opaque_limb(a_in.l[i]); b.l[i] = fp_opaque_limb(b_in.l[i]); }
+#if MNT753_KARATSUBA
+  fp_mul_karatsuba<M>(r.l, a.l, b.l);
+  return;
+#endif
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (int64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += (int64_t)acc2;
+    acc2 = 0;
+    m[k] = ((uint32_t)acc * FPC[M].inv) & LMASK;
+    acc += (int64_t)((uint64_t)m[k] * FPC[M].p[0]);
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += (int64_t)acc2;
+    acc2 = 0;
+    r.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+}
+// a with int32 limbs, |a_i| < 2^29: cross terms once against 2a.  The value is >= 0 whatever the sign of a.
+template <int M>
+HD void fp_sqr_s(Fp<M>& r, const Fp<M>& a_in) {
+  int64_t acc = 0;
+  uint64_t acc2 = 0;
+  uint32_t m[NL];
+  int32_t d[NL];
+  struct { int32_t l[NL]; } a;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { a.l[i] = fp_opaque_limb(a_in.l[i]); d[i] = fp_opaque_limb(a_in.l[i] << 1); }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; ++i) acc += (int64_t)a.l[i] * d[k - i];
+    if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += (int64_t)acc2;
+    acc2 = 0;
+    m[k] = ((uint32_t)acc * FPC[M].inv) & LMASK;
+    acc += (int64_t)((uint64_t)m[k] * FPC[M].p[0]);
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; 2 * i < k; ++i) acc += (int64_t)a.l[i] * d[k - i];
+    if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += (int64_t)acc2;
+    acc2 = 0;
+    r.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+}
+// limb-wise a - b and a +- b (the sign chosen per lane): no carries, signed limbs
+template <int M>
+HD void fp_sub_raw(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] - b.l[i];
+}
+template <int M>
+HD void fp_addsub_raw(Fp<M>& r, const Fp<M>& a, const Fp<M>& y, bool subtract) {
+  const uint32_t mk = subtract ? 0xffffffffu : 0u, one = subtract ? 1u : 0u;   // a + (y ^ mk) + one = a - y
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + (y.l[i] ^ mk) + one;
+}
+// signed un-normalised limbs (|limb| < 2^30 - 2^28 |q|... see above: |value| < 5p) -> [0.49p, 1.51p), limbs in [0, 2^28)
+template <int M>
+HD void fp_norm(Fp<M>& r, const Fp<M>& a) {
+  const float t = (float)(int32_t)a.l[NL - 1] * (1.0f / (float)FPC[M].p[NL - 1]) - 0.5f;
+  int32_t nq = (int32_t)t;              // truncation towards zero ...
+  nq -= (float)nq > t ? 1 : 0;          // ... made a floor: q = floor(top / p_top - 1/2)
+  nq = -nq;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int32_t v = (int32_t)a.l[i] + nq * (int32_t)FPC[M].p[i] + c;
+    if (i < NL - 1) { r.l[i] = (uint32_t)v & LMASK; c = v >> LB; } else r.l[i] = (uint32_t)v;
+  }
+}
+// d = a - b limb-wise with a, b in [0, 2p): d = 0 (mod p) only for d in {-p, 0, p}, whose low 28 bits are 0, p_0 or -p_0 --
+// a test that passes for three values in 2^28; the caller settles the rare hit exactly (fp_sub + fp_is_zero)
+template <int M>
+HD bool fp_raw_maybe_zero(const Fp<M>& d) {
+  const uint32_t t = d.l[0] & LMASK;
+  return t == 0u || t == FPC[M].p[0] || t == ((0u - FPC[M].p[0]) & LMASK);
 }
 
 template <int M>

@@ -11,6 +11,7 @@ int g_window_bits_override = 0;
 float g_last_timing[5] = {0, 0, 0, 0, 0};
 int g_last_plan[4] = {0, 0, 0, 0};
 int g_last_pair_levels = 0;
+int g_point_cus = 256;
 }
 using namespace mnt753;
 
@@ -128,6 +129,12 @@ int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective) {
 int mnt753_msm_set_window_bits(int c) {
   int old = g_window_bits_override;
   g_window_bits_override = (c >= 2 && c <= 22) ? c : 0;
+  return old;
+}
+
+int mnt753_msm_set_point_cus(int cus) {
+  const int old = g_point_cus;
+  if (cus >= 8 && cus <= 256) g_point_cus = cus;
   return old;
 }
 

@@ -25,6 +25,7 @@ extern int g_window_bits_override;
 extern float g_last_timing[5];
 extern int g_last_plan[4];
 extern int g_last_pair_levels;
+extern int g_point_cus;
 }
 namespace {
 
@@ -54,6 +55,20 @@ int pick_precomp_bits(size_t n) {
   return best;
 }
 
+// Compute units the long-running point kernels (pairing levels, accumulate) are sized for: one 256-thread workgroup per CU, every
+// workgroup alive for the whole kernel.  256 = the whole chip (a single MSM has nothing to share it with).  The prover runs five MSMs
+// on five streams, and their latency-bound phases (sort, edge merge, the narrow steps of the bucket reduction: a few workgroups, one
+// group addition deep) only overlap another MSM's point kernels if some CUs are NOT held by them: main_hip sizes the point kernels
+// for 240 (mnt753_msm_set_point_cus), which leaves two CUs per XCD to whatever else is ready.  MNT753_POINT_CUS overrides.
+inline uint32_t point_cus() {
+  if (const char* e = getenv("MNT753_POINT_CUS")) { int v = atoi(e); if (v >= 8 && v <= 256) return (uint32_t)v; }
+  return (uint32_t)g_point_cus;
+}
+// logical lanes one round of those CUs holds: 256 threads per CU, 2 or 3 of them per point for the lane-split fields (21 triples
+// per wave, 84 per CU)
+inline uint32_t machine_lanes(int lanes_per_point) {
+  return lanes_per_point == 3 ? point_cus() * 84u : point_cus() * 256u / (uint32_t)lanes_per_point;
+}
 // lanes_per_point: threads that share one point in the point kernels (1, or 2 / 3 with the lane-split G2 fields); the
 // machine holds 65536 threads at one wave per SIMD, i.e. 65536 / lanes_per_point points at a time
 MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
@@ -68,7 +83,7 @@ MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   const uint64_t entries = (uint64_t)p.W * n;
   int rounds = entries < ((uint64_t)1 << 23) ? 1 : 2;   // small sets: fewer lanes = fewer edge pieces to combine (measured)
   if (const char* e = getenv("MNT753_MSM_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 64) rounds = v; }
-  const uint64_t machine = lanes_per_point == 3 ? 21504u : 65536u / (unsigned)lanes_per_point;   // 21 triples per wave
+  const uint64_t machine = machine_lanes(lanes_per_point);
   uint64_t lanes_target = machine * rounds;
   uint64_t T = (entries + lanes_target - 1) / lanes_target;
   if (T < 16) T = 16;
@@ -282,25 +297,31 @@ void horner_host(const uint64_t* wire_pts, int n_sets, int c, uint64_t* out) {
 }
 
 // Pairing levels (k_pair_level, MNT753_MSM_PAIR = number of levels) + accumulate over the shortened list.
-// Lanes per level: one round of the machine at one wave per SIMD; minimum additions per inversion: keeps its share below one
-// product per addition.  MNT753_PAIR_LANES / MNT753_PAIR_MINB are development overrides.
+// Lanes per level: one round of the machine at one wave per SIMD, every lane in use down to batches of PAIR_MIN_B additions per
+// inversion.  MNT753_PAIR_LANES / MNT753_PAIR_MINB are development overrides.
 inline uint32_t pair_env(const char* name, uint32_t dflt) { const char* e = getenv(name); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; }
 #define PAIR_MAX_LANES pair_env("MNT753_PAIR_LANES", 65536u)
-#define PAIR_MIN_B pair_env("MNT753_PAIR_MINB", 48u)
-// levels of the pairing pass for an MSM with `entries` sorted entries: below the measured crossover the per-level
-// inversion latency and the short batches cost more than the saved products;
-// MNT753_MSM_PAIR=<levels> overrides, 0 turns it off
+#define PAIR_MIN_B pair_env("MNT753_PAIR_MINB", 8u)
+// Levels of the pairing pass for an MSM with `entries` sorted entries, from the one-GPU slice sweep of round 3
+// (tools/slice_sweep.py, profiles/r03/slice_sweep.json: every size an 8-way split of the benchmark configurations produces, levels
+// 0..4).  What a level costs besides its products is one inversion per lane (0.3 ms of wave time whatever the batch length), so
+// the floor on the batch length that round 2 used (48 additions per inversion) was the wrong economy for slices: it left most of
+// the machine idle behind a few lanes -- at 2^18 G1 points three levels take 8.8 ms with batches of 19..76 on every lane and
+// 9.4 ms with the floor, against 10.2 ms without levels.  MNT753_MSM_PAIR=<levels> overrides, 0 turns the pass off.
 template <class V>
 int pair_levels(uint64_t entries) {
   if constexpr (V::F::DEG != 1 && V::F::LANES == 1) return 0;   // one-lane Fq2 / Fq3: the state does not fit, no pairing
   else {
     if (const char* e = getenv("MNT753_MSM_PAIR")) { int v = atoi(e); return v < 0 ? 0 : (v > 6 ? 6 : v); }
-    if constexpr (V::F::LANES == 1) {          // G1: crossover ~2^19 points
-      if (entries >= ((uint64_t)1 << 25)) return 3;
-      if (entries >= ((uint64_t)1 << 24)) return 2;
-    } else {                                   // lane-split G2: more arithmetic per gathered byte, crossover ~2^17 points
+    if constexpr (V::F::LANES == 1) {          // G1: 2^18 points and up (2^17: 5.3 ms plain, 5.5 with two levels)
+      if (entries >= ((uint64_t)1 << 23)) return 3;
+    } else if constexpr (V::F::LANES == 2) {   // two-lane Fq2: more arithmetic per gathered byte, crossover ~2^17 points
       if (entries >= ((uint64_t)1 << 23)) return 3;
       if (entries >= ((uint64_t)1 << 22)) return 2;
+    } else {                                   // three-lane Fq3: its accumulate runs the point VM, levels pay from 2^12 points on
+      if (entries >= ((uint64_t)1 << 20)) return 3;   // MNT6753 2^15: 12.8 ms against 15.0 without
+      if (entries >= ((uint64_t)1 << 19)) return 2;   // 2^14: 9.2 against 10.2
+      if (entries >= ((uint64_t)1 << 17)) return 1;   // 2^13, 2^12: 6.5 / 6.1 against 6.9 / 6.3
     }
     return 0;
   }
@@ -375,7 +396,7 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
   if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
     const int levels = p.pair_levels;
     // logical lanes: one workgroup per CU (the level kernels take 145 KB of LDS), 21 triples per wave for three-lane fields
-    const uint32_t max_lanes = V::F::LANES == 3 ? std::min<uint32_t>(PAIR_MAX_LANES / 3u, 21504u) : PAIR_MAX_LANES / (uint32_t)V::F::LANES;
+    const uint32_t max_lanes = std::min<uint32_t>(machine_lanes(V::F::LANES), V::F::LANES == 3 ? PAIR_MAX_LANES / 3u : PAIR_MAX_LANES / (uint32_t)V::F::LANES);
     const uint32_t min_B = PAIR_MIN_B;
     if (int rc = ensure_pair_ws<V, C>(b, p, n)) return rc;
     HIP_TRY(hipMemsetAsync(b->d_fix, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
@@ -427,10 +448,20 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
     }
     const uint32_t* src = last_rows;
     // accumulate over at most `cap` entries: one round of the machine
-    const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, V::F::LANES == 3 ? 21504u : 65536u / (uint32_t)V::F::LANES);
+    const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, machine_lanes(V::F::LANES));
     const uint32_t T2 = (uint32_t)std::max<uint64_t>((cap + lanes_acc - 1) / lanes_acc, 8);
-    hipLaunchKernelGGL((k_bucket_accumulate<V, true>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, src, b->d_sorted2,
-                       b->d_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
+    {
+      // the blocked accumulate prefetches its rows through 112 KB of dynamic LDS per workgroup: opt in once per kernel and device
+      static std::atomic<uint32_t> acc_lds_set{0};
+      const uint32_t dev_bit = 1u << (b->device & 31);
+      const size_t acc_lds = MNT753_ACC_PREFETCH ? ACC_LDS_BYTES : 0;
+      if (acc_lds && !(acc_lds_set.load(std::memory_order_acquire) & dev_bit)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_accumulate<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
+        acc_lds_set.fetch_or(dev_bit, std::memory_order_release);
+      }
+      hipLaunchKernelGGL((k_bucket_accumulate<V, true>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), acc_lds, st, src, b->d_sorted2,
+                         b->d_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
+    }
     *acc_lanes = lanes_acc;
     return 0;
   } else {

@@ -404,6 +404,23 @@ static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restric
 //                  stride `plane_stride` uint4s, see k_pair_level): consecutive entries of a lane then sit in adjacent 16-byte
 //                  pieces of the same sectors, and the level's stores are contiguous KiB instead of 64 partial sectors each.
 __host__ __device__ __forceinline__ size_t blk_index(uint32_t j);
+__device__ __forceinline__ void glds16(const void* gsrc, const uint4* lds_dst_wave_uniform);
+__device__ __forceinline__ void wait_vm0();
+__device__ __forceinline__ void wait_lgkm0();
+template <int M>
+__device__ __forceinline__ uint32_t fp_from_lds(Fp<M>& r, const uint4* p, uint32_t stride);
+// BLOCKED instantiation, build option -DMNT753_ACC_PREFETCH=1: the rows of a lane's next entry are fetched by LDS-DMA while the
+// current mixed addition runs (two images of 14 quads x 64 lanes per wave, 112 KB per workgroup).  A lane walks its OWN run of
+// slots, so a wave's 64 loads of one piece go to 64 different lines and most of them miss the L1 (SQ counters of round 3: 27 % of
+// the wave cycles waited for them, VALU busy 61 %); one entry ahead that latency hides behind eleven products, with no register
+// spent on it.  Measured neutral (same-box A/B, profiles/r03/ab_acc_prefetch.txt: 22.65 / 22.99 ms without, 22.90 / 22.66 with):
+// the kernel's clock follows its utilisation (2.22 GHz at 61 % VALU-busy, 2.0 GHz at 85 %: the chip is power-limited under this
+// load), so waiting less buys a lower clock, not a shorter kernel.  Off by default: it would only hold 112 KB of LDS.
+constexpr uint32_t ACC_IMG_QUADS = 14u * 64u;
+constexpr uint32_t ACC_LDS_BYTES = 4u * 2u * ACC_IMG_QUADS * 16u;
+#ifndef MNT753_ACC_PREFETCH
+#define MNT753_ACC_PREFETCH 0
+#endif
 #ifndef MNT753_ACC_LINE_SPLIT
 #define MNT753_ACC_LINE_SPLIT 2   // lane-split fields of up to this many lanes per point also take the straight-line addition (measured: two-lane Fq2 -1.0 ms of 72, three-lane Fq3 neutral)
 #endif
@@ -441,7 +458,23 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
   Proj<C> acc, Q;
   pt_set_zero(acc);
   F::one(Q.Z);
-  for (; e < end; ++e) {
+  constexpr bool PREFETCH = BLOCKED && MNT753_ACC_PREFETCH;
+  // PREFETCH: entry e of the blocked list is row e of the planes (k_pair_level, last level: out_sorted[o] = (o << 1) | sign), so the
+  // address of the next row needs no load; only its sign does, and that is read one iteration ahead as well
+  extern __shared__ uint4 acc_lds[];
+  uint4* acc_img = acc_lds + (size_t)(threadIdx.x >> 6) * (2u * ACC_IMG_QUADS);
+  const uint32_t acc_lane = threadIdx.x & 63u;
+  auto issue_row = [=](uint32_t row, uint32_t buf) __attribute__((always_inline)) {
+    const uint4* px = reinterpret_cast<const uint4*>(bases) + (size_t)(row & 1u) * plane_stride + blk_index((row >> 1) * F::LANES + lane_comp<F>());
+#pragma unroll
+    for (uint32_t i = 0; i < 7; ++i) {
+      glds16(px + (size_t)i * 64, acc_img + buf * ACC_IMG_QUADS + i * 64u);
+      glds16(px + 2 * plane_stride + (size_t)i * 64, acc_img + buf * ACC_IMG_QUADS + (7u + i) * 64u);
+    }
+  };
+  uint32_t s_next = 0, it = 0;
+  if constexpr (PREFETCH) { s_next = sorted[e]; issue_row(e, 0u); }
+  for (; e < end; ++e, ++it) {
     if (e == next) {
       // bucket b is finished inside this segment
       if (first_run) {
@@ -454,8 +487,17 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
       acc_zero = true;
       do { ++b; next = offsets[b + 1]; } while (next == e);
     }
-    uint32_t s = sorted[e];
-    if constexpr (BLOCKED) {
+    uint32_t s;
+    if constexpr (PREFETCH) {
+      s = s_next << 31;
+      wait_vm0();                                    // the image of this entry (issued one mixed addition ago)
+      const uint4* im = acc_img + (it & 1u) * ACC_IMG_QUADS + acc_lane;
+      (void)fp_from_lds(Q.X, im, 64u);
+      (void)fp_from_lds(Q.Y, im + 7u * 64u, 64u);
+      wait_lgkm0();
+      if (e + 1u < end) { s_next = sorted[e + 1u]; issue_row(e + 1u, (it + 1u) & 1u); }
+    } else if constexpr (BLOCKED) {
+      s = sorted[e];
       static_assert(F::DEG == 1 || F::LANES > 1, "blocked rows hold one component per thread");
       // entries of the blocked list are (row << 1) | sign: with the sign in bit 31 hipcc 7.2 dropped the mask from
       // (s & 0x7fffffff) >> 7 in the address computation below (s >> 7 fed the 64-bit multiply-add; entries of negated points
@@ -471,6 +513,7 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
         if (4 * i + 3 < NL) { Q.X.l[4 * i + 3] = vx.w; Q.Y.l[4 * i + 3] = vy.w; }
       }
     } else {
+      s = sorted[e];
       const uint32_t* src = bases + (size_t)(s & 0x7fffffffu) * aff_words<C>();
       e_load<F>(Q.X, src);
       e_load<F>(Q.Y, src + F::DEG * FPS_WORDS);
@@ -632,6 +675,9 @@ constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
 #ifndef MNT753_PAIR_FWD_AHEAD
 #define MNT753_PAIR_FWD_AHEAD 1
 #endif
+#ifndef MNT753_PAIR_LAZY
+#define MNT753_PAIR_LAZY 1
+#endif
 #ifndef MNT753_PAIR_OFF_PER_STEP
 #define MNT753_PAIR_OFF_PER_STEP 1     // first level: table offsets of the next slot read per portion (7 registers) instead of per slot (28)
 #endif
@@ -700,6 +746,9 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   // first level of a base field: the table offsets of the next slot's pieces are read out of the entry image ahead of the
   // loads (per portion).  The lane-split fields keep a ds_read in front of every piece: their multiplier leaves no registers.
   constexpr bool PRELOAD = first && LN == 1;
+  // base fields: differences limb-wise without carries, signed-product multiplier, two normalisations per addition instead of
+  // seven carry-propagating subtractions (fp753.hip.h, "lazy arithmetic"); MNT753_PAIR_LAZY=0 builds the eager formulas
+  constexpr bool LAZY = has_lazy<F>::value && MNT753_PAIR_LAZY;
   extern __shared__ uint4 pair_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint4* img = pair_lds + (size_t)wave * PAIR_LDS_WAVE_QUADS;
@@ -856,8 +905,16 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     else if (f1 & PF_EMPTY) kind = PK_SINGLE;
     else {
       kind = PK_ADD;
-      F::sub(den, x2, x1);
-      if (F::is_zero(den)) {
+      bool same_x;
+      if constexpr (LAZY) {
+        F::sub_raw(den, x2, x1);
+        same_x = F::raw_maybe_zero(den);       // three low-limb patterns in 2^28; settled exactly below
+        if (same_x) { E du; F::sub(du, x2, x1); same_x = F::is_zero(du); }
+      } else {
+        F::sub(den, x2, x1);
+        same_x = F::is_zero(den);
+      }
+      if (same_x) {
         // same x: equal points (doubling, denominator 2y) or opposite points (cancellation, take 1).  Rare: plain loads.
         if constexpr (first) {
           const uint2 e = reinterpret_cast<const uint2*>(entries)[o];
@@ -880,12 +937,13 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     tw_a += __builtin_readcyclecounter() - tfa0;
 #endif
     if (kind <= PK_CANCEL) {
-      F::mul(tmp, run, den);
+      if constexpr (LAZY) F::mul_s(tmp, run, den); else F::mul(tmp, run, den);
       run = tmp;
     }
   }
   E inv;
   PAIR_T(tc1);
+  if constexpr (LAZY) { F::norm(tmp, run); run = tmp; }   // signed top limb, (-0.3p, 1.3p) -> [0, 2p) for the inversion
   F::inv(inv, run);
   PAIR_T(tc2);
   // ---- backward: individual inverses and the sums (highest slot of the wave first)
@@ -932,8 +990,13 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     ysave = y1;
     if (kind == PK_ADD) {
       out_flag = f1 & PF_NEG;
-      F::sub(den, x2, x1);
-      fp_addsub<M>(num, y2, y1, !flip);         // y2 - y1  or  y2 + y1
+      if constexpr (LAZY) {
+        F::sub_raw(den, x2, x1);
+        F::addsub_raw(num, y2, y1, !flip);
+      } else {
+        F::sub(den, x2, x1);
+        fp_addsub<M>(num, y2, y1, !flip);         // y2 - y1  or  y2 + y1
+      }
     } else if (kind == PK_DBL) {
       // P1 == P2 as signed points, s1 y1 = s2 y2: lambda = (3 x^2 + a) / (2 s1 y1) = s1 lambda' with the denominator 2 y1 formed
       // exactly as in the forward sweep (y1 + y2, or y1 - y2 when the flags differ); result (x3, s1 (lambda' (x1 - x3) - y1))
@@ -1024,7 +1087,9 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
           case 3: opa = den; opb = den; break;
           default: opa = den; opb = num; break;
         }
-        if constexpr (has_sqr<F>::value) {
+        if constexpr (LAZY) {
+          if (step == 3) F::sqr_s(res, opa); else F::mul_s(res, opa, opb);
+        } else if constexpr (has_sqr<F>::value) {
           if (step == 3) F::sqr(res, opa); else F::mul(res, opa, opb);
         } else {
           F::mul(res, opa, opb);
@@ -1034,12 +1099,25 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
           case 1: inv = res; break;
           case 2: den = res; break;
           case 3:
-            F::sub(res, res, x1);
-            F::sub(x2, res, x2);
-            F::sub(num, x1, x2);
+            if constexpr (LAZY) {
+              // x3 = lambda^2 - x1 - x2 limb-wise, ONE normalisation; x1 - x3 stays raw (it only feeds the last product)
+              F::sub_raw(res, res, x1);
+              F::sub_raw(res, res, x2);
+              F::norm(x2, res);
+              F::sub_raw(num, x1, x2);
+            } else {
+              F::sub(res, res, x1);
+              F::sub(x2, res, x2);
+              F::sub(num, x1, x2);
+            }
             break;
           default:
-            fp_addsub<M>(y1, res, y1, !(kind == PK_ADD && flip));
+            if constexpr (LAZY) {
+              F::addsub_raw(res, res, y1, !(kind == PK_ADD && flip));
+              F::norm(y1, res);
+            } else {
+              fp_addsub<M>(y1, res, y1, !(kind == PK_ADD && flip));
+            }
             break;
         }
       }

@@ -1,4 +1,5 @@
-// ./main_hip <curve> compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--unfused-h] [--ref-order] [--quiet]
+// ./main_hip <curve> compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--point-cus N] [--unfused-h] [--ref-order] [--quiet]
+//            --serve: keep the parameters resident and prove further "<input> <output>" pairs read from stdin, one per line
 // ./main_hip <curve> compute-r1cs <params> <r1cs> <witness> <output> ...      (ca / cb / cc evaluated on the device from the constraint system)
 // ./main_hip <curve> complete <keys> <input|witness> <challenge_proof> <full_proof> [--s-file <Fr> | --s-seed N]
 //
@@ -29,6 +30,8 @@ static bool g_fused_h = true;
 static bool g_quiet = false;
 static bool g_h_first = true;
 static int g_gpus = 0;   // --gpus N: parameter vectors sharded over N devices of this node (0: MNT753_GPUS or 1)
+static bool g_serve = false;    // --serve: after the listed jobs, read further "<input> <output>" lines from stdin until EOF
+static int g_point_cus = 256;   // --point-cus N: CUs the point kernels are sized for (include/mnt753_hip.h, mnt753_msm_set_point_cus)
 
 typedef std::chrono::steady_clock clk;
 static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
@@ -128,7 +131,7 @@ void prove_one(typename B::groth16_params* params, const char* input_path, const
   B::delete_vector_Fr(coefficients_for_H); B::delete_vector_Fr(w); B::delete_vector_Fr(w_off);
   B::delete_vector_Fr(ca); B::delete_vector_Fr(cb); B::delete_vector_Fr(cc);
   B::delete_vector_G1(pA); B::delete_vector_G1(pB1); B::delete_vector_G2(pB2); B::delete_vector_G1(pH); B::delete_vector_G1(pL);
-  (void)r;  // the reference never frees B::field (no delete_field in the wrapper)
+  B::delete_field(r);   // (the reference's wrapper has no delete_field and its driver leaks the element)
   B::delete_groth16_input(input);
 }
 
@@ -136,6 +139,7 @@ void prove_one(typename B::groth16_params* params, const char* input_path, const
 template <typename B>
 void run_prover(const char* params_path, const std::vector<std::pair<std::string, std::string>>& jobs, const char* r1cs_path = nullptr) {
   if (g_gpus > 0) B::use_devices(g_gpus);
+  (void)mnt753_msm_set_point_cus(g_point_cus);
   B::init_public_params();
   auto t0 = clk::now();
   auto params = B::read_params(params_path);
@@ -147,6 +151,25 @@ void run_prover(const char* params_path, const std::vector<std::pair<std::string
     if (!g_quiet && jobs.size() > 1) printf("-- proof %s -> %s\n", job.first.c_str(), job.second.c_str());
     prove_one<B>(params, job.first.c_str(), job.second.c_str(), t0, first, cs);
     first = false;
+  }
+  if (g_serve) {
+    // Resident job feed: the parameters (window tables, workspaces, evaluation domain: ~6 s and ~54 GB of HBM to build for the 2^20
+    // set) are paid once per HOST process, every job after that costs its prove time.  One job per line on stdin,
+    // "<input path> <output path>"; after each, one line "proved <output path> <seconds>" (or "failed <output path>: <reason>") on
+    // stdout, flushed, so a driver can pipeline requests.  EOF ends the service.
+    char line[8192];
+    while (fgets(line, sizeof(line), stdin)) {
+      char in_path[4096], out_path[4096];
+      if (sscanf(line, "%4095s %4095s", in_path, out_path) != 2) continue;
+      const auto tj = clk::now();
+      try {
+        prove_one<B>(params, in_path, out_path, t0, false, cs);
+        printf("proved %s %.3f\n", out_path, secs(tj, clk::now()));
+      } catch (const std::exception& e) {
+        printf("failed %s: %s\n", out_path, e.what());
+      }
+      fflush(stdout);
+    }
   }
   if (cs) B::delete_r1cs(cs);
   B::delete_groth16_params(params);
@@ -234,10 +257,12 @@ int main(int argc, char** argv) {
   for (int i = a0 + 2; i < argc; ++i) {
     if (!strcmp(argv[i], "--repeat") && i + 1 < argc) { repeat = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { g_gpus = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--point-cus") && i + 1 < argc) { g_point_cus = atoi(argv[++i]); continue; }
     if (argv[i][0] != '-' && i + 1 < argc && argv[i + 1][0] != '-') { jobs.emplace_back(argv[i], argv[i + 1]); ++i; continue; }
     if (!strcmp(argv[i], "--fused-h")) g_fused_h = true;
     else if (!strcmp(argv[i], "--unfused-h")) g_fused_h = false;
     else if (!strcmp(argv[i], "--quiet")) g_quiet = true;
+    else if (!strcmp(argv[i], "--serve")) g_serve = true;
     else if (!strcmp(argv[i], "--h-first")) g_h_first = true;
     else if (!strcmp(argv[i], "--h-last") || !strcmp(argv[i], "--ref-order")) g_h_first = false;
   }

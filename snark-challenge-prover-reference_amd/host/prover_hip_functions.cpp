@@ -568,6 +568,7 @@ template <int CURVE> typename HIP_B::vector_G2* HIP_B::params_B2(groth16_params*
 
 template <int CURVE> void HIP_B::delete_G1(G1* a) { if (a) resolve<CURVE>(a); delete a; }
 template <int CURVE> void HIP_B::delete_G2(G2* a) { if (a) resolve<CURVE>(a); delete a; }
+template <int CURVE> void HIP_B::delete_field(field* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_Fr(vector_Fr* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_G1(vector_G1* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_G2(vector_G2* a) { delete a; }

@@ -6,6 +6,11 @@ across GPUs: rank g owns bases[lo_g:hi_g] resident in its HBM, runs the whole Pi
 only exchange is ONE projective point per rank (288 B for G1) -- an all_gather of 36..108 uint64 words, which is
 latency-bound; the xGMI link bandwidth is irrelevant to it.  Elliptic-curve addition is not an RCCL reduction
 operator, so the fold after the gather is W-1 host point additions (microseconds).
+
+The partial result of a rank arrives on the HOST (the last 20 doublings and additions of a bucket reduction are a
+host Horner), so an exchange over RCCL is host -> device -> all_gather -> host.  `PointExchange` keeps
+the four buffers of that round trip (pinned host in / out, device in / out) for the life of the process and uses
+all_gather_into_tensor: no allocation, no tensor list, one synchronisation per exchange.
 """
 import numpy as np
 
@@ -26,18 +31,48 @@ def fold_partials(api, curve, group, partials):
     return acc
 
 
+class PointExchange:
+    """all_gather of `words` uint64 per rank with persistent buffers.  device = torch.device of this rank for RCCL, None for a
+    CPU backend (gloo: the CPU tests and the shared-GPU development mode)."""
+
+    def __init__(self, words, device=None):
+        import torch
+        import torch.distributed as dist
+        self.words, self.device, self.world = int(words), device, dist.get_world_size()
+        # uint64 has no collective support in torch; the words travel as int64 bit patterns
+        self.h_in = torch.empty(self.words, dtype=torch.int64)
+        self.h_out = torch.empty(self.world * self.words, dtype=torch.int64)
+        if device is not None:
+            self.h_in, self.h_out = self.h_in.pin_memory(), self.h_out.pin_memory()
+            self.d_in = torch.empty(self.words, dtype=torch.int64, device=device)
+            self.d_out = torch.empty(self.world * self.words, dtype=torch.int64, device=device)
+
+    def all_gather(self, local_words):
+        """local_words: numpy uint64 [words].  Returns the list of every rank's words (numpy uint64), in rank order."""
+        import torch
+        import torch.distributed as dist
+        self.h_in.numpy()[:] = np.ascontiguousarray(local_words, dtype=np.uint64).view(np.int64)
+        if self.device is not None:
+            self.d_in.copy_(self.h_in, non_blocking=True)
+            dist.all_gather_into_tensor(self.d_out, self.d_in)
+            self.h_out.copy_(self.d_out, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            dist.all_gather_into_tensor(self.h_out, self.h_in)
+        out = self.h_out.numpy().view(np.uint64).reshape(self.world, self.words)
+        return [out[r].copy() for r in range(self.world)]
+
+
+_EXCHANGES = {}
+
+
 def all_gather_points(local_words, device=None):
-    """all_gather one projective point per rank.  local_words: numpy uint64 [W].  Returns list of numpy arrays."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    # uint64 has no collective support in torch; the words travel as int64 bit patterns
-    t = torch.from_numpy(np.ascontiguousarray(local_words, dtype=np.uint64).view(np.int64).copy())
-    if device is not None:
-        t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    return [o.cpu().numpy().view(np.uint64) for o in out]
+    """all_gather one block of words per rank (a projective point, or the five partial points of a proof)."""
+    key = (len(local_words), str(device))
+    ex = _EXCHANGES.get(key)
+    if ex is None:
+        ex = _EXCHANGES[key] = PointExchange(len(local_words), device)
+    return ex.all_gather(local_words)
 
 
 def msm_sharded(api, curve, group, local_partial, device=None):

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the multi-GPU decomposition of an MSM (contiguous slices, one projective point per
+"""CPU, world_size 2 and 4 over gloo: the multi-GPU decomposition of an MSM (contiguous slices, one projective point per
 rank exchanged by all_gather, serial fold) -- with the oracle standing in for the per-rank device MSM, which needs
 a GPU.  The exchange and fold code is the product's (snark-challenge-prover-reference_amd/parallel.py)."""
 import os
@@ -29,13 +29,15 @@ def _worker(rank, world, port, curve, group, n, q):
     local_aff = O.msm(curve, group, pts[lo:hi], sc[lo:hi])            # stand-in for BaseSet.msm on this rank's GPU
     local = pkg.point_from_affine(curve, group, local_aff)
     total = pkg.parallel.msm_sharded(pkg.api, curve, group, local)
+    again = pkg.parallel.msm_sharded(pkg.api, curve, group, local)     # the persistent exchange buffers are reusable
+    assert np.array_equal(total, again)
     q.put((rank, pkg.point_to_affine(curve, group, total).tobytes(), (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("curve,group,n", [(0, 1, 37), (1, 2, 11)])
-def test_sharded_msm_world2(curve, group, n):
+@pytest.mark.parametrize("curve,group,n,world", [(0, 1, 37, 2), (1, 2, 11, 2), (0, 1, 41, 4)])
+def test_sharded_msm_over_gloo(curve, group, n, world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from __graft_entry__ import load_package
     import oracle_lib as O
@@ -43,7 +45,7 @@ def test_sharded_msm_world2(curve, group, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, curve, group, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, curve, group, n, q)) for r in range(world)]
     for p in procs: p.start()
     res = [q.get(timeout=180) for _ in procs]
     for p in procs: p.join(timeout=60)
@@ -51,7 +53,7 @@ def test_sharded_msm_world2(curve, group, n):
     pts = pkg.synth_points(curve, group, 5, n, threads=2)
     sc = pkg.synth_scalars(curve, 6, n)
     expect = O.msm(curve, group, pts, sc).tobytes()
-    assert sorted(r[2] for r in res) == [(0, n // 2), (n // 2, n)]
+    assert sorted(r[2] for r in res) == [pkg.parallel.shard_range(n, r, world) for r in range(world)]
     assert all(r[1] == expect for r in res)
 
 

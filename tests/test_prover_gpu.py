@@ -108,6 +108,22 @@ def test_resident_parameters_batch_mode(gpu, curve, tmp_path):
 
 
 @pytest.mark.parametrize("curve", [0, 1])
+def test_resident_job_feed(gpu, curve, tmp_path):
+    """main_hip --serve: the parameters stay resident in HBM and further (input, output) pairs arrive on stdin, one per line; every
+    proof is the reference's, a bad job is reported and the service goes on (the 6 s table build of a full-size set is paid once per
+    host process, not once per proof)."""
+    params, inp, expected = G.e2e_paths(curve)
+    outs = [str(tmp_path / f"p{k}.bin") for k in range(3)]
+    feed = f"{inp} {outs[1]}\n/nonexistent {tmp_path / 'x'}\n{inp} {outs[2]}\n"
+    r = subprocess.run([EXE, NAME[curve], "compute", params, inp, outs[0], "--serve", "--quiet"], input=feed, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert [l.split()[0] for l in lines] == ["proved", "failed", "proved"]
+    for o in outs:
+        assert filecmp.cmp(o, expected, shallow=False)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
 @pytest.mark.parametrize("n_dev", [2, 3])
 def test_sharded_inside_the_boundary(gpu, curve, n_dev, tmp_path):
     """main_hip --gpus N: ONE process, the five parameter vectors cut into N contiguous slices (multiexp.tcc:417-431), one base

@@ -1,0 +1,95 @@
+"""CPU: the host side of the product under AddressSanitizer + UBSan and under ThreadSanitizer (the reference
+ships sanitizer builds of its host code; GPU sanitizers do not exist on the pool).  `make asan` / `make tsan` build host/main.cpp and
+host/prover_hip_functions.cpp over tools/stub_abi/stub_mnt753.cpp -- a TEST STUB of the C ABI with host memory and no arithmetic --
+so what runs here is exactly the host logic: the input loader thread, the per-device slice loaders, the readiness latches, the
+sharded start / fold, batch mode, and every error path of the CLI.  Results are not compared with anything (an MSM of the stub
+returns the identity); a sanitizer report or a non-zero exit code fails the test."""
+import os
+import subprocess
+
+import pytest
+
+import golden_io as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAME = {0: "MNT4753", 1: "MNT6753"}
+
+
+@pytest.fixture(scope="module")
+def san():
+    r = subprocess.run(["make", "asan", "tsan"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return {k: os.path.join(ROOT, "build", "san", f"main_hip_{k}") for k in ("asan", "tsan")}
+
+
+def run(exe, args, expect_rc=0, leaks=1):
+    env = dict(os.environ, ASAN_OPTIONS=f"detect_leaks={leaks}:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == expect_rc, (r.returncode, r.stderr[-2000:])
+    return r
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
+@pytest.mark.parametrize("curve", [0, 1])
+def test_host_paths_clean_under_sanitizers(san, kind, curve, tmp_path):
+    params, inp, _ = G.e2e_paths(curve)
+    out = str(tmp_path / "o")
+    for flags in ([], ["--repeat", "3"], ["--gpus", "2", "--ref-order"], ["--gpus", "3", "--unfused-h", "--repeat", "2"], ["--gpus", "8"],
+                  [inp, str(tmp_path / "o2"), "--gpus", "4"]):
+        r = run(san[kind], [NAME[curve], "compute", params, inp, out] + flags)
+        assert "Total time from input to output" in r.stdout
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
+def test_resident_job_feed_clean_under_sanitizers(san, kind, tmp_path):
+    """main_hip --serve: jobs read from stdin against resident parameters, a failing job in the middle does not end the service."""
+    params, inp, _ = G.e2e_paths(1)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=1")
+    feed = f"{inp} {tmp_path / 'a'}\n/nonexistent {tmp_path / 'b'}\n{inp} {tmp_path / 'c'}\n"
+    r = subprocess.run([san[kind], "MNT6753", "compute", params, inp, str(tmp_path / "o"), "--serve", "--quiet", "--gpus", "2"], input=feed, capture_output=True,
+                       text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert [l.split()[0] for l in lines] == ["proved", "failed", "proved"]
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
+def test_r1cs_front_end_and_completion_clean_under_sanitizers(san, kind, tmp_path):
+    for curve in (0, 1):
+        d = os.path.join(G.GOLDEN, f"g16_mnt{4 if curve == 0 else 6}")
+        out = str(tmp_path / "o")
+        run(san[kind], [NAME[curve], "compute-r1cs", os.path.join(d, "params.bin"), os.path.join(d, "r1cs.bin"), os.path.join(d, "witness.bin"), out, "--gpus", "2"])
+        run(san[kind], [NAME[curve], "complete", os.path.join(d, "keys.bin"), os.path.join(d, "input.bin"), os.path.join(d, "challenge.bin"), str(tmp_path / "full")])
+
+
+def test_error_paths_clean_under_asan(san, tmp_path):
+    """Every way the CLI can fail: no invalid access on the way out.  Leak checking is off here only: the wrapper keeps the
+    reference's raw-pointer interface (B::read_params returns a `new`-ed object the driver deletes at the end), so an exception that
+    ends the process leaves the objects built so far to the operating system -- as the reference's own driver does."""
+    import functools
+    run_err = functools.partial(run, leaks=0)
+    exe = san["asan"]
+    params, inp, _ = G.e2e_paths(0)
+    out = str(tmp_path / "o")
+    run_err(exe, ["MNT4753", "compute", "/nonexistent", inp, out], expect_rc=1)
+    run_err(exe, ["MNT4753", "compute", params, "/nonexistent", out], expect_rc=1)
+    run_err(exe, ["BN128", "compute", params, inp, out], expect_rc=2)
+    run_err(exe, ["MNT4753"], expect_rc=2)
+    run_err(exe, ["MNT4753", "compute", params, inp, out, "--gpus", "99"], expect_rc=1)
+    raw = bytearray(open(params, "rb").read())
+    (tmp_path / "trunc").write_bytes(bytes(raw[:-8]))
+    run_err(exe, ["MNT4753", "compute", str(tmp_path / "trunc"), inp, out], expect_rc=1)
+    raw[8:16] = (1 << 40).to_bytes(8, "little")
+    (tmp_path / "badhdr").write_bytes(bytes(raw))
+    run_err(exe, ["MNT4753", "compute", str(tmp_path / "badhdr"), inp, out], expect_rc=1)
+    short_in = open(inp, "rb").read()[:-96]
+    (tmp_path / "short_in").write_bytes(short_in)
+    run_err(exe, ["MNT4753", "compute", params, str(tmp_path / "short_in"), out, "--gpus", "2"], expect_rc=1)
+    # a constraint system whose variable count does not match the parameters (the out-of-bounds read of the round-2 advice)
+    d = os.path.join(G.GOLDEN, "g16_mnt4")
+    cs = bytearray(open(os.path.join(d, "r1cs.bin"), "rb").read())
+    cs[8:16] = (int.from_bytes(cs[8:16], "little") + 5).to_bytes(8, "little")
+    (tmp_path / "cs_bad").write_bytes(bytes(cs))
+    r = run_err(exe, ["MNT4753", "compute-r1cs", os.path.join(d, "params.bin"), str(tmp_path / "cs_bad"), os.path.join(d, "witness.bin"), out], expect_rc=1)
+    assert "variables" in r.stderr

@@ -6,7 +6,11 @@ cd "$(dirname "$0")/.."
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 python bench.py > $O/bench_line.json 2> $O/bench_stderr.log
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prove > $O/bench_under_rocprof.json 2>/dev/null
+# exactly the timed loop of the driver's command (20 steps + 5 warm-up of the table-mode 2^20 G1 MSM, nothing else): the per-kernel
+# averages of kt_loop are what `roofline.kernel_ms` and the per-kernel table of DESIGN.md 4.3 must agree with
+rocprofv3 --kernel-trace --stats -d $O/kt_loop -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prove --no-extras > $O/bench_loop_under_rocprof.json 2>/dev/null
+# the other legs (table-less MSM, FFT / compute_H, G2, slice sweep) in a trace of their own
+rocprofv3 --kernel-trace --stats -d $O/kt_extras -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove > $O/bench_extras_under_rocprof.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras > /dev/null 2>&1
 CURVE=0 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2 -o g2 -- python3 $R/tools/dev_msm_big.py 20 3 > $O/g2_msm_2p20.log 2>/dev/null

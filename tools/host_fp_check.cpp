@@ -37,4 +37,49 @@ template <int M> int run() {
   { Fp<M> z, iz; fp_zero(z); fp_inv(iz, z); if (!fp_is_zero(iz)) { ++bad; printf("inv(0) != 0, M=%d\n", M); } }
   return bad;
 }
-int main() { int b = run<0>() + run<1>(); printf(b ? "FAIL %d\n" : "fp_sqr / fp_mul2 / fp_mul3 / fp_inv OK\n", b); return b != 0; }
+// The lazy arithmetic of the pairing levels (fp_mul_s, fp_sqr_s, fp_sub_raw, fp_addsub_raw, fp_norm) against the eager formulas
+// on whole affine additions, chained over several "levels" so that normalised outputs feed the next round: same residues, outputs in
+// [0, 2p) with 28-bit limbs, and the cheap zero test never misses a zero difference.
+template <int M> bool norm_ok(const Fp<M>& a) {   // limbs in [0, 2^28) and p/2 - eps <= a < 3p/2 + eps (loosely: < 2p)
+  for (int i = 0; i < NL; ++i) if (a.l[i] > LMASK) return false;
+  return in_range(a);
+}
+template <int M> int run_lazy() {
+  int bad = 0;
+  for (int it = 0; it < 1500; ++it) {
+    Fp<M> x1, y1, x2, y2, inv, pre;
+    rand_fp(x1); rand_fp(y1); rand_fp(x2); rand_fp(y2); rand_fp(inv); rand_fp(pre);
+    if (it % 7 == 0) { fp_zero(x1); }                       // extreme operands: 0 and values just below 2p
+    if (it % 11 == 0) { Fp<M> z, o; fp_zero(z); fp_one(o); fp_sub(x2, z, o); }
+    Fp<M> ex1 = x1, ey1 = y1, ex2 = x2, ey2 = y2, einv = inv, epre = pre;   // eager twin
+    for (int level = 0; level < 4; ++level) {
+      const bool flip = ((it + level) & 1) != 0;
+      // eager (what k_pair_level computed before round 3)
+      Fp<M> eden, enum_, t, el, ex3, enum2, ey3, ninv, npre;
+      fp_sub(eden, ex2, ex1);
+      if (flip) fp_add(enum_, ey2, ey1); else fp_sub(enum_, ey2, ey1);
+      fp_mul(npre, einv, epre); fp_mul(ninv, einv, eden); fp_mul(el, enum_, npre);
+      fp_sqr(t, el); fp_sub(t, t, ex1); fp_sub(ex3, t, ex2); fp_sub(enum2, ex1, ex3);
+      fp_mul(t, el, enum2); if (flip) fp_add(ey3, t, ey1); else fp_sub(ey3, t, ey1);
+      // lazy
+      Fp<M> den, num, l, res, x3, num2, y3, linv, lpre;
+      fp_sub_raw(den, x2, x1);
+      if (fp_is_zero(eden) && !fp_raw_maybe_zero(den)) { ++bad; printf("zero test missed M=%d\n", M); }
+      fp_addsub_raw(num, y2, y1, !flip);
+      fp_mul_s(lpre, inv, pre); fp_mul_s(linv, inv, den); fp_mul_s(l, num, lpre);
+      fp_sqr_s(res, l); fp_sub_raw(res, res, x1); fp_sub_raw(res, res, x2); fp_norm(x3, res); fp_sub_raw(num2, x1, x3);
+      fp_mul_s(res, l, num2); fp_addsub_raw(res, res, y1, !flip); fp_norm(y3, res);
+      Fp<M> linv_n, lpre_n;
+      fp_norm(linv_n, linv); fp_norm(lpre_n, lpre);
+      if (!eq(x3, ex3) || !eq(y3, ey3) || !eq(linv_n, ninv) || !eq(lpre_n, npre) || !norm_ok(x3) || !norm_ok(y3) || !norm_ok(linv_n)) {
+        ++bad; if (bad < 6) printf("lazy slot mismatch M=%d it=%d level=%d\n", M, it, level);
+      }
+      // next level: the outputs meet a fresh point; the running inverse stays SIGNED (as in the kernel's backward sweep)
+      x1 = x3; y1 = y3; ex1 = ex3; ey1 = ey3;
+      rand_fp(x2); rand_fp(y2); ex2 = x2; ey2 = y2;
+      inv = linv; einv = ninv; pre = lpre; epre = npre;
+    }
+  }
+  return bad;
+}
+int main() { int b = run<0>() + run<1>() + run_lazy<0>() + run_lazy<1>(); printf(b ? "FAIL %d\n" : "fp_sqr / fp_mul2 / fp_mul3 / fp_inv / lazy arithmetic OK\n", b); return b != 0; }
