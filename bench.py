@@ -79,6 +79,56 @@ def respawn_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
+# ---- PMC traffic of the dominant phase, measured in this run ---------------------------------------------------------
+def live_traffic():
+    """FETCH_SIZE / WRITE_SIZE of the bucket-accumulation kernels of one 2^20 G1 MSM, from two rocprofv3 --pmc passes over a short
+    run of this same script (child processes, started before this process touches the GPU; counters in their own runs with no trace
+    domains, as the microarch guide prescribes).  Units and the gfx950 correction as in its HBM section: counters in KB, FETCH_SIZE
+    doubled (128-B requests tallied at 64 B for 16-B-per-lane loads; the row gathers of the first level are an uncalibrated pattern, so
+    the raw sum is reported beside it).  Returns None when rocprofv3 is not there or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    if shutil.which("rocprofv3") is None:
+        return None
+    per = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-prove", "--no-extras", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            con = sqlite3.connect(dbs[0]); cur = con.cursor()
+            t = [x[0] for x in cur.execute("select name from sqlite_master where type='table'")]
+            kd = [x for x in t if "kernel_dispatch" in x][0]; ks = [x for x in t if "kernel_symbol" in x][0]
+            pm = [x for x in t if "pmc_event" in x][0]; pi = [x for x in t if "info_pmc" in x][0]
+            q = (f"select s.display_name, e.value from {pm} e join {pi} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id "
+                 f"join {ks} s on d.kernel_id = s.id where p.symbol = '{ctr}'")
+            acc = {}
+            for name, val in cur.execute(q):
+                n = name.split("(")[0].replace("void mnt753::", "")
+                if n.startswith("k_pair_level<mnt753::Mnt4G1") or n.startswith("k_bucket_accumulate<mnt753::Mnt4G1") or n.startswith("k_pair_fix<mnt753::Mnt4G1"):
+                    acc.setdefault(n, []).append(val)
+            con.close()
+            msms = max((len(v) for k, v in acc.items() if k.startswith("k_bucket_accumulate")), default=0)
+            if msms == 0:
+                return None
+            per[ctr] = {k: sum(v) / msms for k, v in acc.items()}
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f_kb, w_kb = sum(per["FETCH_SIZE"].values()), sum(per["WRITE_SIZE"].values())
+    return {"source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (2 timed MSMs + 1 warm-up each)",
+            "FETCH_SIZE_KB_per_msm": f_kb, "WRITE_SIZE_KB_per_msm": w_kb, "raw_bytes_per_msm": (f_kb + w_kb) * 1024,
+            "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024,
+            "per_kernel_FETCH_KB": per["FETCH_SIZE"], "per_kernel_WRITE_KB": per["WRITE_SIZE"],
+            "correction": "MI355X_MICROARCH.md, HBM: KB units; FETCH_SIZE x 2 on gfx950 for 16-B-per-lane loads (gathers uncalibrated: raw figure beside it)"}
+
+
 # ---- CPU baseline ------------------------------------------------------------------------------------------
 def cpu_baseline(pkg, pts, sc, np):
     """The reference's own multi_exp (BDLO12, chunks = host threads -- what B::multiexp_G1 runs) through oracle/_ref/ref_msm_bench
@@ -88,8 +138,9 @@ def cpu_baseline(pkg, pts, sc, np):
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_msm_bench")
     cores = os.cpu_count() or 1
     if os.access(ref, os.X_OK):
-        # >= 2^17 points per chunk would need cores * 2^17 points; bound the sample at 2^19 (about 10-30 s on a large host)
-        n2 = min(1 << 19, len(pts))
+        # the whole benchmark input (2^20 pairs: ~25 s on the 256 host threads of an MI355X box): the reference's result then
+        # cross-checks exactly what was timed; BENCH_CPU_SAMPLE_LOG2 shrinks the sample on small hosts
+        n2 = min(1 << int(os.environ.get("BENCH_CPU_SAMPLE_LOG2", "20")), len(pts))
         with tempfile.NamedTemporaryFile(dir=os.environ.get("TMPDIR", "/tmp"), suffix=".bin") as f:
             pts[:n2].tofile(f); sc[:n2].tofile(f); f.flush()
             r = subprocess.run([ref, f.name, str(n2)], capture_output=True, text=True)
@@ -98,7 +149,7 @@ def cpu_baseline(pkg, pts, sc, np):
             j = json.loads(lines[-1])
             got = np.array([int(j["result_affine_hex"][16 * i:16 * i + 16], 16) for i in range(24)], dtype=np.uint64)
             return dict(value=j["points_per_s"], unit="points/s", cores=j["threads"], kind="reference",
-                        sample=f"first 2^{n2.bit_length() - 1} (base, scalar) pairs of the benchmark input; libff multi_exp_with_mixed_addition<BDLO12> of the "
+                        sample=f"{'all' if n2 == len(pts) else 'first'} 2^{n2.bit_length() - 1} (base, scalar) pairs of the benchmark input; libff multi_exp_with_mixed_addition<BDLO12> of the "
                                f"reference compiled by oracle/build_ref.sh, {j['threads']} OpenMP chunks of {n2 // j['threads']} points, {j['seconds']:.1f} s"), got, n2
     import oracle_lib as O
     threads = O.lib().oracle_max_threads()
@@ -229,6 +280,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true", help="skip the full-prove leg (N = 1 runs it by default)")
     ap.add_argument("--no-extras", action="store_true", help="skip the FFT / compute_H / G2 / table-less legs")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure the HBM traffic of the dominant phase")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -244,6 +296,9 @@ def main():
     legs = None
     if world == 1 and not args.no_prove and args.log_n == LOG_N:
         legs = prove_legs()
+    traffic_live = None
+    if world == 1 and not args.no_traffic and args.log_n == LOG_N:
+        traffic_live = live_traffic()
 
     import numpy as np
     import torch
@@ -355,16 +410,23 @@ def main():
         # PMC traffic of the same phase (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh); quoted only
         # while the kernel sources are the ones it was measured on
         traffic, traffic_info = None, None
-        tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "accumulate_traffic.json")
-        if os.path.exists(tpath) and args.log_n == LOG_N and world == 1:
-            tj = json.load(open(tpath))
-            if tj.get("kernels_fingerprint") == kernels_fingerprint():
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_info = {"source": f"profiles/{PROFILE_ROUND}/accumulate_traffic.json", "kernels_fingerprint": tj.get("kernels_fingerprint"),
-                                "achieved_GBps": traffic / (acc * 1e-3) / 1e9 if traffic else None,
-                                "frac_of_hbm_peak": traffic / (acc * 1e-3) / 1e9 / HBM_PEAK_GBPS if traffic else None}
-            else:
-                traffic_info = {"stale": True, "note": "profiles traffic was measured on different kernel sources; re-run tools/collect_profiles.sh"}
+        if traffic_live:
+            traffic = traffic_live["hbm_bytes_per_launch"]
+            traffic_info = dict(traffic_live, achieved_GBps=traffic / (acc * 1e-3) / 1e9, frac_of_hbm_peak=traffic / (acc * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                raw_over_algorithmic=traffic_live["raw_bytes_per_msm"] / (ALGO_BYTES_PER_PAIR * n_local))
+        else:
+            # no live passes (rocprofv3 absent, --no-traffic, N > 1): the figure of profiles/, quoted only while the kernel sources are
+            # the ones it was measured on
+            tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "accumulate_traffic.json")
+            if os.path.exists(tpath) and args.log_n == LOG_N and world == 1:
+                tj = json.load(open(tpath))
+                if tj.get("kernels_fingerprint") == kernels_fingerprint():
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_info = {"source": f"profiles/{PROFILE_ROUND}/accumulate_traffic.json", "kernels_fingerprint": tj.get("kernels_fingerprint"),
+                                    "achieved_GBps": traffic / (acc * 1e-3) / 1e9 if traffic else None,
+                                    "frac_of_hbm_peak": traffic / (acc * 1e-3) / 1e9 / HBM_PEAK_GBPS if traffic else None}
+                else:
+                    traffic_info = {"stale": True, "note": "profiles traffic was measured on different kernel sources; re-run tools/collect_profiles.sh"}
         line = {
             "metric": "G1 MSM points/sec at 2^20 (MNT4753)",
             "value": value,
@@ -403,9 +465,12 @@ def main():
     if world == 1:
         if not args.no_cpu_baseline:
             base, got, n2 = cpu_baseline(pkg, pts, sc, np)
-            chk = pkg.BaseSet(0, 1, pts[:n2])
-            same = bool(np.array_equal(pkg.point_to_affine(0, 1, chk.msm(sc[:n2])), got))
-            chk.close()
+            if n2 == n:      # the reference ran the whole benchmark input: compare with the result of the timed loop itself
+                same = bool(np.array_equal(pkg.point_to_affine(0, 1, out), got))
+            else:
+                chk = pkg.BaseSet(0, 1, pts[:n2])
+                same = bool(np.array_equal(pkg.point_to_affine(0, 1, chk.msm(sc[:n2])), got))
+                chk.close()
             base["matches_gpu_on_sample"] = same
             line["cpu_baseline"] = base
             ok = ok and same

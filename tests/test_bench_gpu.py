@@ -1,0 +1,41 @@
+"""GPU: the N > 1 flow of bench.py -- the north-star split of ONE array into contiguous slices, one rank per slice, all_gather of
+one projective point per rank, serial fold (multiexp.tcc:417-440) -- on the one-GPU test box: BENCH_SHARE_GPU=1 lets the ranks share
+the device and exchange over gloo, everything else (slicing, the strong headline, the weak object, parity through the discrete logs,
+max-over-ranks timing, the JSON contract) is the code the driver's multi-GPU run executes over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_flow(gpu, world):
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-n", "13"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["steps"] == 2 and j["warmup"] == 1
+    assert j["scaling"] == "strong" and j["parity_ok"] is True
+    assert j["config"]["points"] == 1 << 13 and j["config"]["points_per_gpu"] in ((1 << 13) // world, (1 << 13) - ((1 << 13) // world) * (world - 1))
+    assert j["weak"]["scaling"] == "weak" and j["weak"]["parity_ok"] is True
+    assert j["value"] > 0 and j["weak"]["value"] > 0 and j["unit"] == "points/s"
+    for key in ("metric", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert key in j
+
+
+def test_bench_single_gpu_contract_small(gpu):
+    """The N = 1 line at a small size: every field of the contract, no prove / extras legs (those need the 2^20 workload)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "13", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["parity_ok"] is True
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])

@@ -4,7 +4,13 @@
 #   guide prescribes), kernel stats of a G2 MSM, and the full-size proves.  usage: tools/collect_profiles.sh
 cd "$(dirname "$0")/.."
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
-python bench.py > $O/bench_line.json 2> $O/bench_stderr.log
+python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_stderr.log
+# round 3: the slice sweep behind pair_levels() and the predicted 1/2/4/8-GPU curve, board power / clocks under load, the compiler
+# reproducers, and the N > 1 flow of bench.py on the shared device (gloo)
+python3 tools/slice_sweep.py --out $O/slice_sweep.json > $O/slice_sweep.log 2>&1
+sh tools/experiments/power_sample.sh > $O/power_and_clocks.txt 2>&1
+sh tools/compiler_repro/check.sh > $O/compiler_repro.log 2>&1
+BENCH_SHARE_GPU=1 python3 bench.py --gpus 4 --steps 5 --warmup 2 > $O/bench_4ranks_shared_gpu.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 # exactly the timed loop of the driver's command (20 steps + 5 warm-up of the table-mode 2^20 G1 MSM, nothing else): the per-kernel
 # averages of kt_loop are what `roofline.kernel_ms` and the per-kernel table of DESIGN.md 4.3 must agree with
@@ -24,6 +30,7 @@ M=$R/snark-challenge-prover-reference_amd/main_hip
 { echo "== main_hip MNT4753 d = 2^20 - 1, three proofs against resident parameters"; $M MNT4753 compute $K/p4 $K/i4 $K/o4 --repeat 3; sha256sum $K/o4;
   echo "== the reference's call order and its unfused compute_H (--ref-order --unfused-h)"; $M MNT4753 compute $K/p4 $K/i4 $K/o4r --ref-order --unfused-h | grep -i "total\|load"; sha256sum $K/o4r;
   echo "== two logical devices sharing the one GPU of this box (MNT753_SHARE_DEVICE=1 --gpus 2)"; MNT753_SHARE_DEVICE=1 $M MNT4753 compute $K/p4 $K/i4 $K/o4s --gpus 2 --repeat 2 | grep -i "total\|load"; sha256sum $K/o4s;
+  echo "== eight logical devices sharing the one GPU (MNT753_SHARE_DEVICE=1 --gpus 8): every code path of the 8-way split, none of its speed"; MNT753_SHARE_DEVICE=1 $M MNT4753 compute $K/p4 $K/i4 $K/o4e --gpus 8 --repeat 2 | grep -i "total\|load"; sha256sum $K/o4e;
   echo "== reference-minted hashes (tests/golden/oracle_hashes.json)"; grep output_sha256 tests/golden/oracle_hashes.json; } > $O/full_prove_MNT4753_2p20.log 2>&1
 { echo "== main_hip MNT6753 d = 2^15 - 1"; $M MNT6753 compute $K/p6 $K/i6 $K/o6 --repeat 3; sha256sum $K/o6;
   echo "== CPU: the reference prover (oracle/_ref/main, $(nproc) hardware threads)"; if [ -x oracle/_ref/main ]; then oracle/_ref/main MNT6753 compute $K/p6 $K/i6 $K/o6ref 2>&1 | grep -i "total time"; sha256sum $K/o6ref; fi;
