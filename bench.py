@@ -297,7 +297,8 @@ def main():
     if world == 1 and not args.no_prove and args.log_n == LOG_N:
         legs = prove_legs()
     traffic_live = None
-    if world == 1 and not args.no_traffic and args.log_n == LOG_N:
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+    if world == 1 and not args.no_traffic and args.log_n == LOG_N and not under_profiler:   # (a profiled run has the GPU initialised already)
         traffic_live = live_traffic()
 
     import numpy as np

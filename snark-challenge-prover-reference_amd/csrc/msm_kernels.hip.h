@@ -678,6 +678,9 @@ constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
 #ifndef MNT753_PAIR_LAZY
 #define MNT753_PAIR_LAZY 1
 #endif
+#ifndef MNT753_PAIR_SPLIT_PRELOAD
+#define MNT753_PAIR_SPLIT_PRELOAD 0
+#endif
 #ifndef MNT753_PAIR_OFF_PER_STEP
 #define MNT753_PAIR_OFF_PER_STEP 1     // first level: table offsets of the next slot read per portion (7 registers) instead of per slot (28)
 #endif
@@ -746,6 +749,8 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   // first level of a base field: the table offsets of the next slot's pieces are read out of the entry image ahead of the
   // loads (per portion).  The lane-split fields keep a ds_read in front of every piece: their multiplier leaves no registers.
   constexpr bool PRELOAD = first && LN == 1;
+  // backward sweep only: the per-portion offsets (seven registers, AGPRs will do) for the lane-split fields as well
+  constexpr bool PRELOAD_BWD = first && (LN == 1 || MNT753_PAIR_SPLIT_PRELOAD);
   // base fields: differences limb-wise without carries, signed-product multiplier, two normalisations per addition instead of
   // seven carry-propagating subtractions (fp753.hip.h, "lazy arithmetic"); MNT753_PAIR_LAZY=0 builds the eager formulas
   constexpr bool LAZY = has_lazy<F>::value && MNT753_PAIR_LAZY;
@@ -981,7 +986,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     // blocked index (uint4 units) of the next slot's element: the per-lane part of the addresses of its planes and prefix product
     const uint32_t vb_next = more ? (uint32_t)blk_index(min((it - 1u) * NLe + (lane_on ? t : t0w), S - 1u) * LN + comp) : 0u;
     uint32_t off[ROW_PIECES];
-    if constexpr (PRELOAD && !MNT753_PAIR_OFF_PER_STEP) { if (more) load_row_offsets((n + 1u) & 1u, std::false_type{}, off); }
+    if constexpr (PRELOAD_BWD && !MNT753_PAIR_OFF_PER_STEP) { if (more) load_row_offsets((n + 1u) & 1u, std::false_type{}, off); }
     wait_lgkm0();
     if constexpr (first) { if (more) issue_entries(it >= 2u ? it - 2u : 0u, n & 1u); }
     const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
@@ -1037,7 +1042,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
           auto portion = [=](auto step_c, const uint32_t (&off)[ROW_PIECES], uint32_t vb) __attribute__((always_inline)) {
             constexpr uint32_t base = decltype(step_c)::value * PER_STEP;
             uint32_t offp[PER_STEP];
-            if constexpr (PRELOAD && MNT753_PAIR_OFF_PER_STEP) {
+            if constexpr (PRELOAD_BWD && MNT753_PAIR_OFF_PER_STEP) {
               // the table offsets of this portion out of the entry image, one wait for all of them
 #pragma unroll
               for (uint32_t u = 0; u < PER_STEP; ++u) offp[u] = base + u < ROW_PIECES ? row_offset((n + 1u) & 1u, base + u) : 0u;
@@ -1047,7 +1052,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
             for (uint32_t u = 0; u < PER_STEP; ++u) {
               const uint32_t idx = base + u;
               if (idx < ROW_PIECES) {
-                if constexpr (PRELOAD) {
+                if constexpr (PRELOAD_BWD) {
                   uint32_t o = MNT753_PAIR_OFF_PER_STEP ? offp[u] : off[idx < ROW_PIECES ? idx : 0u];
                   asm volatile("" : "+v"(o));
                   glds16(table + o, img + 64u * idx);

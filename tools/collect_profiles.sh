@@ -14,11 +14,11 @@ BENCH_SHARE_GPU=1 python3 bench.py --gpus 4 --steps 5 --warmup 2 > $O/bench_4ran
 cd /tmp && export TMPDIR=/tmp
 # exactly the timed loop of the driver's command (20 steps + 5 warm-up of the table-mode 2^20 G1 MSM, nothing else): the per-kernel
 # averages of kt_loop are what `roofline.kernel_ms` and the per-kernel table of DESIGN.md 4.3 must agree with
-rocprofv3 --kernel-trace --stats -d $O/kt_loop -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prove --no-extras > $O/bench_loop_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/kt_loop -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prove --no-extras --no-traffic > $O/bench_loop_under_rocprof.json 2>/dev/null
 # the other legs (table-less MSM, FFT / compute_H, G2, slice sweep) in a trace of their own
-rocprofv3 --kernel-trace --stats -d $O/kt_extras -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove > $O/bench_extras_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt_extras -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-traffic > $O/bench_extras_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras --no-traffic > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras --no-traffic > /dev/null 2>&1
 CURVE=0 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2 -o g2 -- python3 $R/tools/dev_msm_big.py 20 3 > $O/g2_msm_2p20.log 2>/dev/null
 CURVE=1 GROUP=2 rocprofv3 --kernel-trace --stats -d $O/kt_g2m6 -o g2 -- python3 $R/tools/dev_msm_big.py 15 3 > $O/g2_mnt6_msm_2p15.log 2>/dev/null
 cd $R

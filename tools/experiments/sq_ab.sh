@@ -1,7 +1,7 @@
 # GPU box: SQ counters of the level / accumulate kernels for library variants (build_exp/<variant>/libmnt753_hip.so), one
 # rocprofv3 --pmc pass per counter group and variant:  sh tools/experiments/sq_ab.sh <variant> ...   -> gpurun_out/sq_ab/<variant>.txt
 R=$PWD; O=$R/gpurun_out/sq_ab; mkdir -p $O
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras --no-traffic"
 for v in "$@"; do
   L=$R/build_exp/$v/libmnt753_hip.so
   (cd /tmp && export TMPDIR=/tmp MNT753_LIB=$L &&

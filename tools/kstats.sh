@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 R=$PWD; TAG=${1:-run}; shift
 O=$R/gpurun_out/kstats; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/$TAG -o $TAG -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prove --no-extras "$@" > $O/$TAG.json 2>$O/$TAG.err
+rocprofv3 --kernel-trace --stats -d $O/$TAG -o $TAG -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prove --no-extras --no-traffic "$@" > $O/$TAG.json 2>$O/$TAG.err
 cd $R
 python3 - "$O" "$TAG" <<'PY'
 import sqlite3, glob, os, csv, collections, sys

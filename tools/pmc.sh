@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 R=$PWD; TAG=$1; shift
 O=$R/gpurun_out/pmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc "$@" -d $O/$TAG -o $TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras > $O/$TAG.log 2>&1
+rocprofv3 --kernel-trace --pmc "$@" -d $O/$TAG -o $TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras --no-traffic > $O/$TAG.log 2>&1
 cd $R
 python3 - "$O" "$TAG" <<'PY'
 import sqlite3, glob, os, csv, collections, sys

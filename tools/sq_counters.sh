@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 R=$PWD; O=$R/gpurun_out/sq; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $O/counters_list.txt 2>&1
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-prove --no-extras --no-traffic"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_IFETCH -d $O/p1 -o p1 -- python3 $R/bench.py $ARGS > $O/p1.log 2>&1
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAVES -d $O/p2 -o p2 -- python3 $R/bench.py $ARGS > $O/p2.log 2>&1
 cd $R
