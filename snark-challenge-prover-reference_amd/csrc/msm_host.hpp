@@ -496,7 +496,18 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
     const unsigned gs = (n_slots + 255) / 256, gv = blocks_for<typename V::F>(n_slots);
     HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));
     uint32_t level = 0;
+    static const bool edge_pair = !(getenv("MNT753_EDGE_PAIR") && atoi(getenv("MNT753_EDGE_PAIR")) == 0);
     for (uint32_t dist = 1; dist < n_slots; dist <<= 1, ++level) {
+      if constexpr (V::F::LANES == 3) {
+        // three-lane Fq3: a level is one projective addition deep (110 us through the VM); two triples per addition
+        if (edge_pair && (mask & 2u)) {
+          hipLaunchKernelGGL((k_edge_level_sum_pair<V>), dim3((n_slots + 39) / 40), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
+                             b->d_edge_flags, level);
+          hipLaunchKernelGGL((k_edge_level_copy<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
+                             b->d_edge_flags, level);
+          continue;
+        }
+      }
       if (mask & 2u)
         hipLaunchKernelGGL((k_edge_level_sum<V>), dim3(gv), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
                            b->d_edge_flags, level);
@@ -533,6 +544,16 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
       } else if constexpr (V::F::LANES == 2) {
         if (pair_tail && (mask & 4u) && 4 * items <= pair_max) {
           hipLaunchKernelGGL((k_reduce_step_pair<V>), dim3((unsigned)((4 * items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
+          continue;
+        }
+      } else if constexpr (V::F::LANES == 3) {
+        // three-lane Fq3: six lanes per addition, ten additions per wave.  Measured and NOT used (round 3, MNT6753 G2 2^15: reduction
+        // 4.2 ms through the VM, 10.0 ms with this kernel -- ten instead of twenty-one additions per wave and ~270 ds_bpermute per
+        // addition on top of the multiplier's own exchanges); MNT753_REDUCE_PAIR3=1 turns it on.  The edge merge, one addition per
+        // level whatever the width, does gain from the same addition core (k_edge_level_sum_pair: 4.65 -> 4.21 ms).
+        static const bool pair3 = getenv("MNT753_REDUCE_PAIR3") && atoi(getenv("MNT753_REDUCE_PAIR3")) != 0;
+        if (pair3 && pair_tail && (mask & 4u) && 6 * items <= 4 * pair_max) {
+          hipLaunchKernelGGL((k_reduce_step_pair<V>), dim3((unsigned)((items + 39) / 40)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
           continue;
         }
       }

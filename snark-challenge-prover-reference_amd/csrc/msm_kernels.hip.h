@@ -1332,32 +1332,129 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_reduce_step(const uint32
 // (ds_bpermute with the neighbour lane).  Same group element as pt_vm<PC_ADD> (mnt4753_g1.cpp:134-207: add-1998-cmo-2);
 // identities are resolved before, equal points (a doubling) fall back to the VM in the even half.  Base fields, and the
 // two-lane Fq2 with four lanes per addition.
-template <int M, int DIST>
-__device__ __forceinline__ void fp_pair_xchg(Fp<M>& r, const Fp<M>& a) {      // the value of lane ^ DIST
-  const int src = (int)(((threadIdx.x & 63u) ^ (uint32_t)DIST) << 2);
+// the value the partner lane holds (src4 = partner lane * 4)
+template <int M>
+__device__ __forceinline__ void fp_pair_xchg(Fp<M>& r, const Fp<M>& a, int src4) {
 #pragma unroll
-  for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)a.l[i]);
+  for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)a.l[i]);
 }
 template <int M>
 __device__ __forceinline__ void fp_pick(Fp<M>& r, bool c, const Fp<M>& a, const Fp<M>& b) {   // c ? a : b
 #pragma unroll
   for (int i = 0; i < NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
 }
+// Lanes of one addition: LN lanes hold the first point, the next LN lanes the second (LN = lanes per point: 1, 2, or 3 with 21
+// triples per wave -- ten pairs of triples, lanes 60..63 idle).  pair_geometry gives this thread's half, its partner lane and the
+// index of its addition inside the wave.
+template <class F>
+struct PairGeom {
+  bool odd, valid;          // second half of the pair; the wave has a pair for this thread at all
+  int partner4;             // partner lane * 4 (ds_bpermute address)
+  uint32_t pair_in_wave;    // 0 .. PAIRS_PER_WAVE - 1
+  static constexpr uint32_t PAIRS_PER_WAVE = F::LANES == 3 ? 10u : 32u / (uint32_t)F::LANES;
+};
+template <class F>
+__device__ __forceinline__ PairGeom<F> pair_geometry() {
+  PairGeom<F> g;
+  const uint32_t lane = threadIdx.x & 63u;
+  if constexpr (F::LANES == 3) {
+    const uint32_t triple = lane / 3u;                 // 0 .. 20, 21 for lane 63
+    g.odd = (triple & 1u) != 0;
+    g.valid = triple < 20u;
+    g.pair_in_wave = g.valid ? triple >> 1 : 9u;
+    g.partner4 = (int)((g.valid ? (g.odd ? lane - 3u : lane + 3u) : lane) << 2);
+  } else {
+    constexpr uint32_t LN = F::LANES;
+    g.odd = ((lane / LN) & 1u) != 0;
+    g.valid = true;
+    g.pair_in_wave = lane / (2u * LN);
+    g.partner4 = (int)((lane ^ LN) << 2);
+  }
+  return g;
+}
+// the rare equal-points case of the two-lane addition: a real call, so that the VM's registers are not part of the common path's
+// allocation (inlined, the three-lane kernels spilled 500 registers and the step ran 2.4x slower than through the VM)
+template <class C>
+__device__ __attribute__((noinline)) void pt_vm_add_outlined(Proj<C>& P, const Proj<C>& Q, int pc) { pt_vm<C, true>(P, Q, pc); }
+// S + T with TWO point-lanes per addition.  The 12 products + 2 squarings of a projective addition are five dependency levels
+// deep; two halves run them as 3 + 1 + 2 + 1 + 1 = 8 sequential products: the odd half holds the operands swapped (S = its first
+// operand, T = its second), so the first level is the same code in both halves, later levels pick their operands by parity and
+// exchange one element each (ds_bpermute with the partner lane).  Same group element as pt_vm<PC_ADD> (mnt4753_g1.cpp:134-207:
+// add-1998-cmo-2); identities are resolved by the caller's flags, equal points (a doubling) fall back to the VM in the even half.
+// Every lane of the wave must call this (the exchanges need the partner); the sum is valid in the EVEN half only.
+template <class C>
+__device__ __forceinline__ void pt_add_pairlanes(Proj<C>& out, const Proj<C>& S, const Proj<C>& T, bool odd, int partner4) {
+  using F = typename C::F;
+  using E = typename F::E;
+  constexpr int M = F::MOD;
+  const bool zS = pt_is_zero(S), zT = pt_is_zero(T);
+  // level 1: X1Z2, Y1Z2, Z1Z2 (even) | X2Z1, Y2Z1, Z1Z2 (odd)
+  E t1, t2, t3, o, x1z2, x2z1, y1z2, y2z1, u, v;
+  F::mul(t1, S.X, T.Z);
+  F::mul(t2, S.Y, T.Z);
+  F::mul(t3, S.Z, T.Z);
+  fp_pair_xchg<M>(o, t1, partner4); fp_pick<M>(x1z2, odd, o, t1); fp_pick<M>(x2z1, odd, t1, o);
+  fp_pair_xchg<M>(o, t2, partner4); fp_pick<M>(y1z2, odd, o, t2); fp_pick<M>(y2z1, odd, t2, o);
+  F::sub(v, x2z1, x1z2);
+  F::sub(u, y2z1, y1z2);
+  const bool same = F::is_zero(u) && F::is_zero(v);
+  // level 2: vv (even) | uu (odd)
+  E sq, vv, uu, vvv, m, R, uuZ, Aq, RA;
+  fp_pick<M>(m, odd, u, v);
+  if constexpr (has_sqr<F>::value) F::sqr(sq, m); else F::mul(sq, m, m);
+  fp_pair_xchg<M>(o, sq, partner4); fp_pick<M>(vv, odd, o, sq); fp_pick<M>(uu, odd, sq, o);
+  // level 3: vvv (both), R = vv X1Z2 (even) | uu Z1Z2 (odd)
+  F::mul(vvv, v, vv);
+  {
+    E a, b;
+    fp_pick<M>(a, odd, uu, vv); fp_pick<M>(b, odd, t3, x1z2);
+    F::mul(m, a, b);
+  }
+  fp_pair_xchg<M>(o, m, partner4); fp_pick<M>(R, odd, o, m); fp_pick<M>(uuZ, odd, m, o);
+  F::sub(Aq, uuZ, vvv); F::sub(Aq, Aq, R); F::sub(Aq, Aq, R);      // A = uu Z1Z2 - vvv - 2R
+  F::sub(RA, R, Aq);
+  // level 4: X3 = v A (even) | vvv Y1Z2 (odd)
+  E m3, m4, o3, o4;
+  {
+    E a, b;
+    fp_pick<M>(a, odd, vvv, v); fp_pick<M>(b, odd, y1z2, Aq);
+    F::mul(m3, a, b);
+  }
+  fp_pair_xchg<M>(o3, m3, partner4);
+  // level 5: u (R - A) (even) | Z3 = vvv Z1Z2 (odd)
+  {
+    E a, b;
+    fp_pick<M>(a, odd, vvv, u); fp_pick<M>(b, odd, t3, RA);
+    F::mul(m4, a, b);
+  }
+  fp_pair_xchg<M>(o4, m4, partner4);
+  if (zS || zT) {                       // identities: S + 0 = S, 0 + T = T
+    out = zT ? S : T;
+  } else if (same) {                    // equal points: the VM's addition turns into its doubling
+    out = S;
+    pt_vm_add_outlined<C>(out, T, odd ? PC_END : PC_ADD);
+  } else {
+    out.X = m3;
+    F::sub(out.Y, m4, o3);
+    out.Z = o4;
+  }
+}
+// The halving step with two point-lanes per addition, for the narrow steps (one addition deep whatever their width: 15 of the 19
+// steps of a 2^19-bucket reduction, 78 us each with one lane per addition).  Base fields (2 lanes per addition), the two-lane Fq2
+// (4) and, since round 3, the three-lane Fq3 (6: its steps took 177 us through the VM).
 template <class C>
 __global__ void __launch_bounds__(256, 1) k_reduce_step_pair(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ A, uint32_t* __restrict__ G, uint32_t n_sets, uint32_t k, uint32_t s) {
   using F = typename C::F;
-  using E = typename F::E;
-  static_assert((F::LANES == 1 && F::DEG == 1) || F::LANES == 2, "base fields and the two-lane Fq2");
-  constexpr int M = F::MOD;
-  constexpr uint32_t LN = F::LANES;            // lanes per point: an addition takes 2 * LN lanes, partners are LN apart
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool odd = ((tid / LN) & 1u) != 0;
+  static_assert((F::LANES == 1 && F::DEG == 1) || F::LANES == 2 || F::LANES == 3, "base fields and the lane-split extension fields");
+  const PairGeom<F> g = pair_geometry<F>();
+  const bool odd = g.odd;
   const uint32_t per_set = red_items(k, s);
-  // both halves of a pair always run together (the exchanges need the neighbour): pairs beyond the list repeat the last item
+  // both halves of a pair always run together (the exchanges need the partner): pairs beyond the list repeat the last item
   const uint32_t n_items = n_sets * per_set;
-  const bool live = tid / (2u * LN) < n_items;
-  const uint32_t t = live ? tid / (2u * LN) : n_items - 1u;
+  const uint32_t item = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PairGeom<F>::PAIRS_PER_WAVE + g.pair_in_wave;
+  const bool live = g.valid && item < n_items;
+  const uint32_t t = item < n_items ? item : n_items - 1u;
   constexpr int PW = proj_words<C>();
   const uint32_t set = t / per_set, r0 = t - set * per_set;
   const uint32_t nb = 1u << k, nh = 1u << (k - s - 1);
@@ -1370,78 +1467,52 @@ __global__ void __launch_bounds__(256, 1) k_reduce_step_pair(const uint32_t* __r
     dst = A + ((size_t)set * nb + red_off_a(k, s + 1) + r0) * PW;
   } else {
     const uint32_t sh = k - s - 2, r = r0 - nh, l = r >> sh, j = r & ((1u << sh) - 1u);
-    uint32_t* g = G + ((size_t)set * nb + red_off_g(k, l)) * PW;
+    uint32_t* gt = G + ((size_t)set * nb + red_off_g(k, l)) * PW;
     const uint32_t half = 1u << (k - l - 2);
     if (l == s) {
       i0 = 4u * j + 1u; i1 = i0 + 2u; src = a_src;
-      dst = g + (size_t)j * PW;
+      dst = gt + (size_t)j * PW;
     } else {
-      i0 = 2u * j; i1 = i0 + 1u; src = g + (size_t)(((s - l - 1u) & 1u) * half) * PW;
-      dst = g + (size_t)(((s - l) & 1u) * half + j) * PW;
+      i0 = 2u * j; i1 = i0 + 1u; src = gt + (size_t)(((s - l - 1u) & 1u) * half) * PW;
+      dst = gt + (size_t)(((s - l) & 1u) * half + j) * PW;
     }
   }
-  // S = this lane's first operand, T = its second: the odd lane holds them swapped
+  // S = this lane's first operand, T = its second: the odd half holds them swapped
   const uint32_t iS = odd ? i1 : i0, iT = odd ? i0 : i1;
   const bool from_buckets = s == 0 && src == a_src;
   const bool eS = from_buckets && offsets[(size_t)set * nb + iS + 1] == offsets[(size_t)set * nb + iS];
   const bool eT = from_buckets && offsets[(size_t)set * nb + iT + 1] == offsets[(size_t)set * nb + iT];
-  Proj<C> S, T;
+  Proj<C> S, T, out;
   if (eS) pt_set_zero(S); else proj_load<C>(S, src + (size_t)iS * PW);
   if (eT) pt_set_zero(T); else proj_load<C>(T, src + (size_t)iT * PW);
-  const bool zS = pt_is_zero(S), zT = pt_is_zero(T);
-  // level 1: X1Z2, Y1Z2, Z1Z2 (even) | X2Z1, Y2Z1, Z1Z2 (odd)
-  E t1, t2, t3, o, x1z2, x2z1, y1z2, y2z1, u, v;
-  F::mul(t1, S.X, T.Z);
-  F::mul(t2, S.Y, T.Z);
-  F::mul(t3, S.Z, T.Z);
-  fp_pair_xchg<M, (int)LN>(o, t1); fp_pick<M>(x1z2, odd, o, t1); fp_pick<M>(x2z1, odd, t1, o);
-  fp_pair_xchg<M, (int)LN>(o, t2); fp_pick<M>(y1z2, odd, o, t2); fp_pick<M>(y2z1, odd, t2, o);
-  F::sub(v, x2z1, x1z2);
-  F::sub(u, y2z1, y1z2);
-  const bool same = F::is_zero(u) && F::is_zero(v);
-  // level 2: vv (even) | uu (odd)
-  E sq, vv, uu, vvv, m, R, uuZ, Aq, RA;
-  fp_pick<M>(m, odd, u, v);
-  if constexpr (has_sqr<F>::value) F::sqr(sq, m); else F::mul(sq, m, m);
-  fp_pair_xchg<M, (int)LN>(o, sq); fp_pick<M>(vv, odd, o, sq); fp_pick<M>(uu, odd, sq, o);
-  // level 3: vvv (both), R = vv X1Z2 (even) | uu Z1Z2 (odd)
-  F::mul(vvv, v, vv);
-  {
-    E a, b;
-    fp_pick<M>(a, odd, uu, vv); fp_pick<M>(b, odd, t3, x1z2);
-    F::mul(m, a, b);
-  }
-  fp_pair_xchg<M, (int)LN>(o, m); fp_pick<M>(R, odd, o, m); fp_pick<M>(uuZ, odd, m, o);
-  F::sub(Aq, uuZ, vvv); F::sub(Aq, Aq, R); F::sub(Aq, Aq, R);      // A = uu Z1Z2 - vvv - 2R
-  F::sub(RA, R, Aq);
-  // level 4: X3 = v A (even) | vvv Y1Z2 (odd)
-  E m3, m4, o3, o4;
-  {
-    E a, b;
-    fp_pick<M>(a, odd, vvv, v); fp_pick<M>(b, odd, y1z2, Aq);
-    F::mul(m3, a, b);
-  }
-  fp_pair_xchg<M, (int)LN>(o3, m3);
-  // level 5: u (R - A) (even) | Z3 = vvv Z1Z2 (odd)
-  {
-    E a, b;
-    fp_pick<M>(a, odd, vvv, u); fp_pick<M>(b, odd, t3, RA);
-    F::mul(m4, a, b);
-  }
-  fp_pair_xchg<M, (int)LN>(o4, m4);
+  pt_add_pairlanes<C>(out, S, T, odd, g.partner4);
   if (odd || !live) return;
-  Proj<C> out;
-  if (zS || zT) {                       // identities: S + 0 = S, 0 + T = T
-    out = zT ? S : T;
-  } else if (same) {                    // equal points: the VM's addition turns into its doubling
-    out = S;
-    pt_vm<C, true>(out, T, PC_ADD);
-  } else {
-    out.X = m3;
-    F::sub(out.Y, m4, o3);
-    out.Z = o4;
-  }
   proj_store<C>(dst, out);
+}
+// Edge merge level with two point-lanes per addition (same addition core): slot j adds slot j + dist when both belong to one bucket.
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_edge_level_sum_pair(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
+                                                               uint32_t* __restrict__ tmp, uint32_t n_slots, uint32_t dist,
+                                                               uint32_t* __restrict__ flags, uint32_t level) {
+  using F = typename C::F;
+  if (level > 0 && flags[level - 1] == 0) return;   // wave-uniform: nothing left to do
+  const PairGeom<F> g = pair_geometry<F>();
+  const uint32_t j = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PairGeom<F>::PAIRS_PER_WAVE + g.pair_in_wave;
+  bool act = g.valid && j < n_slots && j + dist < n_slots;
+  uint32_t b = EDGE_NONE;
+  if (act) { b = edge_bucket[j]; act = b != EDGE_NONE && edge_bucket[j + dist] == b; }
+  // a wave none of whose pairs has work leaves together; otherwise every lane runs the addition (the exchanges need the partner)
+  if (__ballot(act) == 0ull) return;
+  constexpr int PW = proj_words<C>();
+  const uint32_t jj = act ? j : 0u;
+  const uint32_t iS = g.odd ? jj + dist : jj, iT = g.odd ? jj : jj + dist;
+  Proj<C> S, T, out;
+  if (act) { proj_load<C>(S, edges + (size_t)iS * PW); proj_load<C>(T, edges + (size_t)iT * PW); }
+  else { pt_set_zero(S); pt_set_zero(T); }
+  pt_add_pairlanes<C>(out, S, T, g.odd, g.partner4);
+  if (g.odd || !act) return;
+  proj_store<C>(tmp + (size_t)j * PW, out);
+  flags[level] = 1;
 }
 // One lane per addition without the VM: the same formulas in a straight line (14 products), for the wide steps of a base field
 // (a round of the VM's addition takes ~90 us, its switch machine and operand routing included).
