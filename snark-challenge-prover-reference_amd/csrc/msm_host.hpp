@@ -20,6 +20,9 @@
 
 using namespace mnt753;
 
+#ifndef MNT753_SORT_DEFAULT
+#define MNT753_SORT_DEFAULT SORT_PART
+#endif
 namespace mnt753 {
 extern int g_window_bits_override;
 extern float g_last_timing[5];
@@ -135,7 +138,7 @@ void free_pair_ws(mnt753_bases* b) {
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_rank, b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
                   b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage,
-                  b->d_keys_out, b->d_vals_out, b->d_dense, b->d_sort_tmp};
+                  b->d_keys_out, b->d_vals_out, b->d_dense, b->d_sort_tmp, b->d_part_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   free_pair_ws(b);
   if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
@@ -143,17 +146,20 @@ void free_ws(mnt753_bases* b) {
   b->d_edge_tmp = b->d_edge_flags = nullptr;
   b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
   b->h_wire_out = nullptr; b->d_scalars_stage = nullptr;
-  b->d_keys_out = b->d_vals_out = b->d_dense = nullptr; b->d_sort_tmp = nullptr; b->sort_tmp_bytes = 0;
+  b->d_keys_out = b->d_vals_out = b->d_dense = nullptr; b->d_sort_tmp = nullptr; b->sort_tmp_bytes = 0; b->d_part_ws = nullptr;
   b->ws_n = 0;
   b->sorted_cap = 0;
 }
 
-// Sort stage by rocPRIM radix sort (msm_sort.hip) from 2^22 entries on: below, its handful of launches cost more than the
-// atomics it saves.  MNT753_MSM_SORT=atomic / radix overrides.
-inline bool use_radix_sort(uint64_t entries) {
-  if (const char* e = getenv("MNT753_MSM_SORT")) return strcmp(e, "atomic") != 0;
-  return entries >= ((uint64_t)1 << 22);
+// Sort stage from 2^22 entries on: the pairs go through a device-wide sort instead of the histogram-atomic counting sort (below that
+// its handful of launches cost more than the atomics it saves).  Two of them (msm_sort.hip): the hand-written two-level counting
+// sort ("part", round 3) and rocPRIM's radix sort ("radix", round 2).  MNT753_MSM_SORT=atomic / radix / part overrides.
+enum SortMode { SORT_ATOMIC = 0, SORT_RADIX = 1, SORT_PART = 2 };
+inline SortMode sort_mode(uint64_t entries) {
+  if (const char* e = getenv("MNT753_MSM_SORT")) return !strcmp(e, "atomic") ? SORT_ATOMIC : (!strcmp(e, "radix") ? SORT_RADIX : SORT_PART);
+  return entries >= ((uint64_t)1 << 22) ? MNT753_SORT_DEFAULT : SORT_ATOMIC;
 }
+inline bool use_radix_sort(uint64_t entries) { return sort_mode(entries) != SORT_ATOMIC; }   // needs the (key, value) buffers
 template <class C>
 int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   // entries of the sorted list: every bucket padded to a multiple of 2^pair_levels
@@ -177,10 +183,10 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
     b->sort_tmp_bytes = msm_sort_temp_bytes((size_t)p.W * n);
     if (b->sort_tmp_bytes == 0 || hipMalloc(&b->d_keys_out, sizeof(uint32_t) * (size_t)p.W * n) != hipSuccess ||
         hipMalloc(&b->d_vals_out, sizeof(uint32_t) * (size_t)p.W * n) != hipSuccess || hipMalloc(&b->d_dense, sizeof(uint32_t) * ((size_t)p.n_buckets + 2)) != hipSuccess ||
-        hipMalloc(&b->d_sort_tmp, b->sort_tmp_bytes) != hipSuccess) {
+        hipMalloc(&b->d_sort_tmp, b->sort_tmp_bytes) != hipSuccess || hipMalloc(&b->d_part_ws, sizeof(uint32_t) * msm_sort_partition_ws_words()) != hipSuccess) {
       (void)hipGetLastError();
-      for (void* q : {(void*)b->d_keys_out, (void*)b->d_vals_out, (void*)b->d_dense, b->d_sort_tmp}) if (q) (void)hipFree(q);
-      b->d_keys_out = b->d_vals_out = b->d_dense = nullptr; b->d_sort_tmp = nullptr; b->sort_tmp_bytes = 0;
+      for (void* q : {(void*)b->d_keys_out, (void*)b->d_vals_out, (void*)b->d_dense, b->d_sort_tmp, (void*)b->d_part_ws}) if (q) (void)hipFree(q);
+      b->d_keys_out = b->d_vals_out = b->d_dense = nullptr; b->d_sort_tmp = nullptr; b->sort_tmp_bytes = 0; b->d_part_ws = nullptr;
     }
   }
   HIP_TRY(hipMalloc(&b->d_buckets, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
@@ -599,7 +605,11 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   const uint32_t* d_aff = p.pre ? b->d_aff : b->d_aff + base_offset * aff_words<C>();
   const uint8_t* d_inf = b->d_inf + base_offset;
   HIP_TRY(hipEventRecord(b->ev[0], st));
-  if (b->d_sort_tmp && use_radix_sort((uint64_t)p.W * n)) {
+  if (b->d_part_ws && sort_mode((uint64_t)p.W * n) == SORT_PART && msm_sort_partition_fits(p.n_buckets, p.W)) {
+    if (int rc = msm_sort_partition(C::FR, d_scal, d_inf, n, p, p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u, b->d_keys_out, b->d_vals_out,
+                                    b->d_part_ws, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, st))
+      return rc;
+  } else if (b->d_sort_tmp && use_radix_sort((uint64_t)p.W * n)) {
     if (int rc = msm_sort_radix(C::FR, d_scal, d_inf, n, p, p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u,
                                 reinterpret_cast<uint32_t*>(b->d_digits), b->d_rank, b->d_keys_out, b->d_vals_out, b->d_sort_tmp, b->sort_tmp_bytes, b->d_dense,
                                 b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, st))

@@ -1,13 +1,16 @@
-// Sort stage of an MSM for large inputs: (bucket, table row) pairs ordered by bucket with rocPRIM's radix sort instead of
-// the histogram-atomic counting sort of msm_kernels.hip.h.
+// Sort stage of an MSM for large inputs (from 2^22 list entries): (bucket, table row) pairs ordered by bucket, instead of the
+// histogram-atomic counting sort of msm_kernels.hip.h.
 //
-// The counting sort issues one returning atomic per non-zero digit -- 38 * 2^20 = 40 M of them into a 2 MB histogram that
-// every XCD updates, so they are executed at the memory side at ~20 G atomics/s: 1.9 ms, plus 1.3 ms for the scatter that
-// re-reads digits and ranks.  Here: k_scalar_keys writes (key = bucket, value = row | sign) pairs without any atomic (zero
-// digits get the sentinel key n_buckets and sort to the end), rocprim::radix_sort_pairs orders them (39.8 M pairs, 20 key
-// bits: 1.0 ms measured, tools/experiments/sort_bench.hip), k_bucket_bounds finds every bucket's start in the sorted keys by
-// bisection, the usual scan turns the counts into (padded) offsets and k_expand copies the values to their padded positions.
-// The order of the entries inside a bucket differs from the counting sort's; the MSM result is a sum and does not depend on it.
+// That counting sort issues one returning atomic per non-zero digit -- 38 * 2^20 = 40 M of them into a 2 MB histogram that
+// every XCD updates, executed at the memory side at ~20 G atomics/s: 1.9 ms, plus 1.3 ms for the scatter that re-reads digits and
+// ranks.  Two device-wide stages live here, both without an atomic per entry:
+//   * msm_sort_partition (round 3, the default): a hand-written two-level counting sort with the Booth-digit extraction and the
+//     slot-tree padding fused in -- 1.10-1.19 ms at 2^20 G1 points, see the comment above its kernels;
+//   * msm_sort_radix (round 2, MNT753_MSM_SORT=radix): k_scalar_keys writes (key = bucket, value = row | sign) pairs (zero digits get
+//     the sentinel key n_buckets and sort to the end), rocprim::radix_sort_pairs orders them (39.8 M pairs, 20 key bits), k_bucket_bounds
+//     finds every bucket's start by bisection, the usual scan turns the counts into padded offsets, k_expand copies the values to
+//     their padded positions -- 1.33 ms.
+// The order of the entries inside a bucket differs between the stages; the MSM result is a sum and does not depend on it.
 // Group-independent, hence its own translation unit (rocPRIM is not pulled into the four point-arithmetic units).
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -75,6 +78,198 @@ __global__ void __launch_bounds__(256) k_expand(const uint32_t* __restrict__ key
   const uint32_t k = keys[i];
   sorted[((size_t)offsets[k] << shift) + (i - dense[k])] = vals[i];
 }
+// ---- hand-written sort stage (round 3): two-level counting sort ----------------------------------------------------------------
+// The keys are bucket numbers below 2^19..2^21 and nothing needs the order inside a bucket, so a comparison-free two-level counting
+// sort does with ~1.2 GB of traffic what three onesweep passes do with ~2.2 GB, and the Booth-digit extraction and the padding of the
+// slot tree fuse into its passes:
+//   level 1  partitions of PART_BUCKETS = 1024 consecutive buckets.  k_part_count: a block of 256 scalars extracts its 38 x 256
+//            digits, histograms them over the partitions in LDS and adds its counts to the global totals (one atomic per block and
+//            non-empty partition).  k_part_scan: exclusive scan of the totals (one block).  k_part_place: the same block extracts the
+//            digits again (cheaper than keeping them), reserves a range in every partition it feeds (one atomic each) and writes its
+//            (bucket, entry) pairs there, ranked inside the block by LDS atomics: no atomic per entry ever reaches memory.
+//   level 2  chunks of CHUNK = 8192 pairs of the partition-ordered list, whatever partitions they span (work is split by ENTRIES, so
+//            a skewed digit distribution -- all scalars equal, half of them one -- costs no more than a uniform one).
+//            k_bucket_count: LDS histogram over the 1024 buckets of a spanned partition, flushed to the global bucket histogram (one
+//            atomic per chunk and non-empty bucket); the usual scan turns it into padded offsets (k_scan_blocks / _sums / _finish);
+//            k_bucket_place: counts again, reserves per bucket, writes the entries to their padded positions; k_bucket_pad writes the
+//            ENTRY_EMPTY padding of every bucket's last group (no 160 MB memset).
+constexpr uint32_t PART_BITS = 10, PART_BUCKETS = 1u << PART_BITS, PART_MAX = 4096, SORT_CHUNK = 8192;
+
+template <int FRM>
+__device__ __forceinline__ void scalar_to_lds(const uint32_t* __restrict__ scal_wire, const uint8_t* __restrict__ inf, size_t i, size_t n, uint32_t* sw, int tid) {
+  uint32_t w[24], s[24];
+  if (i < n) {
+    load_wire24(w, scal_wire + i * 24);
+    fp_wire_to_integer<FRM>(s, w);
+  }
+  if (i >= n || inf[i]) {
+#pragma unroll
+    for (int j = 0; j < 24; ++j) s[j] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < 24; ++j) sw[j * 256 + tid] = s[j];   // each lane only reads back its own column: no barrier needed
+}
+__device__ __forceinline__ int32_t booth_digit(const uint32_t* sw, int tid, int w, int c) {
+  const int pos = w * c;
+  const uint32_t win = lds_bits(sw + tid, 256, pos, c);
+  const uint32_t blo = pos ? lds_bits(sw + tid, 256, pos - 1, 1) : 0u;
+  const uint32_t top = (win >> (c - 1)) & 1u;
+  return (int32_t)win + (int32_t)blo - (int32_t)(top << c);
+}
+// exclusive scan of v over the 256 threads of a block (LDS scratch of 256 words); returns the prefix of this thread
+__device__ __forceinline__ uint32_t block256_exclusive_scan(uint32_t v, uint32_t* scratch) {
+  const uint32_t t = threadIdx.x;
+  scratch[t] = v;
+  __syncthreads();
+  for (uint32_t o = 1; o < 256; o <<= 1) {
+    const uint32_t y = t >= o ? scratch[t - o] : 0u;
+    __syncthreads();
+    scratch[t] += y;
+    __syncthreads();
+  }
+  return scratch[t] - v;
+}
+// dynamic LDS of the placing pass: scalar words, partition histogram / local starts / global bases, scan scratch, the block's
+// (key, value) pairs (W per scalar); of the counting pass: scalar words and the histogram
+inline size_t part_place_lds(uint32_t n_parts, int W) { return sizeof(uint32_t) * (24u * 256u + 3u * (size_t)n_parts + 256u + 2u * 256u * (size_t)W); }
+constexpr size_t PART_LDS_LIMIT = 160u * 1024u;
+template <int FRM, bool PLACE>
+__global__ void __launch_bounds__(256) k_part_pass(const uint32_t* __restrict__ scal_wire, const uint8_t* __restrict__ inf, size_t n, int c, int W,
+                                                  uint32_t hist_stride, uint32_t entry_stride, uint32_t entry_base, uint32_t n_parts,
+                                                  uint32_t* __restrict__ part_total, uint32_t* __restrict__ part_cursor,
+                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  extern __shared__ uint32_t part_lds[];
+  uint32_t* sw = part_lds;                       // [24][256]
+  uint32_t* hist = sw + 24 * 256;                // [n_parts]
+  const int tid = threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + tid;
+  scalar_to_lds<FRM>(scal_wire, inf, i, n, sw, tid);
+  for (uint32_t p = tid; p < n_parts; p += 256) hist[p] = 0;
+  __syncthreads();
+  for (int w = 0; w < W; ++w) {
+    const int32_t d = booth_digit(sw, tid, w, c);
+    if (d) atomicAdd(&hist[((uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1u) >> PART_BITS], 1u);
+  }
+  __syncthreads();
+  if constexpr (!PLACE) {
+    for (uint32_t p = tid; p < n_parts; p += 256) { const uint32_t cnt = hist[p]; if (cnt) atomicAdd(&part_total[p], cnt); }
+  } else {
+    // The block's pairs are first ordered by partition in LDS and then written out: consecutive threads write consecutive entries of
+    // one partition's range.  Written straight from the digit loop every lane of a store went to a different partition (64 partial
+    // sectors per instruction): 0.55 ms for 318 MB.
+    uint32_t* lstart = hist + n_parts;           // [n_parts] start of the partition inside the block's ordered list
+    uint32_t* base = lstart + n_parts;           // [n_parts] start of the block's range inside the partition (global)
+    uint32_t* scratch = base + n_parts;          // [256]
+    uint32_t* st_k = scratch + 256;              // [256 * W]
+    uint32_t* st_v = st_k + 256u * (uint32_t)W;
+    // local exclusive scan of the partition counts: thread t owns partitions [t * per, (t + 1) * per)
+    const uint32_t per = (n_parts + 255u) / 256u;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t p = tid * per + k; if (p < n_parts) mine += hist[p]; }
+    uint32_t run = block256_exclusive_scan(mine, scratch);
+    for (uint32_t k = 0; k < per; ++k) {
+      const uint32_t p = tid * per + k;
+      if (p < n_parts) {
+        const uint32_t cnt = hist[p];
+        lstart[p] = run; run += cnt;
+        base[p] = cnt ? atomicAdd(&part_cursor[p], cnt) : 0u;
+        hist[p] = 0;
+      }
+    }
+    __syncthreads();
+    const uint32_t block_total = scratch[255];
+    for (int w = 0; w < W; ++w) {
+      const int32_t d = booth_digit(sw, tid, w, c);
+      if (!d) continue;
+      const uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1u;
+      const uint32_t p = key >> PART_BITS;
+      const uint32_t j = lstart[p] + atomicAdd(&hist[p], 1u);
+      st_k[j] = key;
+      st_v[j] = ((uint32_t)w * entry_stride + entry_base + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < block_total; j += 256) {
+      const uint32_t key = st_k[j], p = key >> PART_BITS;
+      const uint32_t pos = base[p] + (j - lstart[p]);
+      keys[pos] = key;
+      vals[pos] = st_v[j];
+    }
+  }
+}
+// exclusive scan of the partition totals (n_parts <= PART_MAX, one block): part_start[0 .. n_parts], cursor = copy of the starts
+__global__ void __launch_bounds__(1024) k_part_scan(const uint32_t* __restrict__ part_total, uint32_t* __restrict__ part_start, uint32_t* __restrict__ part_cursor,
+                                                   uint32_t n_parts) {
+  __shared__ uint32_t tmp[1024];
+  const uint32_t t = threadIdx.x;
+  uint32_t v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const uint32_t p = 4 * t + k; v[k] = p < n_parts ? part_total[p] : 0u; s += v[k]; }
+  tmp[t] = s;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024; o <<= 1) {
+    const uint32_t y = t >= o ? tmp[t - o] : 0u;
+    __syncthreads();
+    tmp[t] += y;
+    __syncthreads();
+  }
+  uint32_t ex = tmp[t] - s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t p = 4 * t + k;
+    if (p < n_parts) { part_start[p] = ex; part_cursor[p] = ex; }
+    ex += v[k];
+  }
+  if (t == 1023) part_start[n_parts] = tmp[1023];
+}
+// one chunk of the partition-ordered (key, value) list; PLACE = false: bucket histogram, PLACE = true: entries to their padded places
+template <bool PLACE>
+__global__ void __launch_bounds__(1024) k_bucket_pass(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ part_start,
+                                                     uint32_t n_parts, uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
+                                                     uint32_t* __restrict__ sorted, uint32_t shift) {
+  __shared__ uint32_t cnt[PART_BUCKETS];
+  __shared__ uint32_t base[PLACE ? PART_BUCKETS : 1];
+  const uint32_t total = part_start[n_parts];
+  const uint32_t lo = blockIdx.x * SORT_CHUNK;
+  if (lo >= total) return;
+  const uint32_t hi = min(lo + SORT_CHUNK, total);
+  // first partition that reaches into the chunk: largest p with part_start[p] <= lo
+  uint32_t a = 0, b = n_parts - 1u;
+  while (a < b) { const uint32_t mid = (a + b + 1u) >> 1; if (part_start[mid] <= lo) a = mid; else b = mid - 1u; }
+  for (uint32_t p = a; p < n_parts; ++p) {
+    const uint32_t ps = part_start[p], pe = part_start[p + 1];
+    if (ps >= hi) break;
+    const uint32_t s = max(ps, lo), e = min(pe, hi);
+    if (s >= e) continue;
+    const uint32_t b0 = p << PART_BITS;
+    for (uint32_t k = threadIdx.x; k < PART_BUCKETS; k += 1024) cnt[k] = 0;
+    __syncthreads();
+    for (uint32_t k = s + threadIdx.x; k < e; k += 1024) atomicAdd(&cnt[keys[k] - b0], 1u);
+    __syncthreads();
+    if constexpr (!PLACE) {
+      for (uint32_t k = threadIdx.x; k < PART_BUCKETS; k += 1024) { const uint32_t v = cnt[k]; if (v) atomicAdd(&hist[b0 + k], v); }
+    } else {
+      for (uint32_t k = threadIdx.x; k < PART_BUCKETS; k += 1024) {
+        const uint32_t v = cnt[k];
+        base[k] = v ? (offsets[b0 + k] << shift) + atomicAdd(&hist[b0 + k], v) : 0u;   // hist was zeroed again after the scan: entries placed so far
+        cnt[k] = 0;
+      }
+      __syncthreads();
+      for (uint32_t k = s + threadIdx.x; k < e; k += 1024) {
+        const uint32_t kb = keys[k] - b0;
+        sorted[base[kb] + atomicAdd(&cnt[kb], 1u)] = vals[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+// the unused tail of every bucket's last group of 2^shift entries
+__global__ void __launch_bounds__(256) k_bucket_pad(const uint32_t* __restrict__ placed, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t shift,
+                                                   uint32_t n_buckets) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_buckets) return;
+  const uint32_t c = placed[b], start = offsets[b] << shift, end = offsets[b + 1] << shift;
+  for (uint32_t k = start + c; k < end; ++k) sorted[k] = 0xffffffffu;   // ENTRY_EMPTY
+}
 unsigned key_bits(uint32_t sentinel) { unsigned b = 1; while ((1ull << b) <= sentinel) ++b; return b; }
 }  // namespace
 
@@ -111,5 +306,51 @@ int msm_sort_radix(int frm, const uint32_t* d_scal, const uint8_t* d_inf, size_t
   hipLaunchKernelGGL(k_expand, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, dense, d_offsets, d_sorted, pshift, p.n_buckets);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+// part_ws: 3 * (PART_MAX + 1) u32 (totals, starts, cursors)
+int msm_sort_partition(int frm, const uint32_t* d_scal, const uint8_t* d_inf, size_t n, const MsmPlan& p, uint32_t entry_stride, uint32_t entry_base,
+                       uint32_t* keys_out, uint32_t* vals_out, uint32_t* part_ws, uint32_t* d_hist, uint32_t* d_offsets, uint32_t* d_cursor,
+                       uint32_t* d_blocksums, uint32_t* d_total, uint32_t* d_sorted, hipStream_t st) {
+  const size_t total = (size_t)p.W * n;
+  const uint32_t n_parts = (p.n_buckets + PART_BUCKETS - 1u) >> PART_BITS;
+  if (n_parts > PART_MAX || total >= 0xffffffffull) return set_error(MNT753_EINVAL, "msm_sort_partition: too many buckets or entries");
+  uint32_t *part_total = part_ws, *part_start = part_ws + (PART_MAX + 1), *part_cursor = part_ws + 2 * (PART_MAX + 1);
+  const unsigned gb = (unsigned)((n + 255) / 256);
+  const uint32_t hs = p.pre ? 0u : p.nb;
+  const uint32_t pshift = (uint32_t)p.pair_levels;
+  HIP_TRY(hipMemsetAsync(part_total, 0, sizeof(uint32_t) * (PART_MAX + 1), st));
+  HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
+  const size_t lds_place = part_place_lds(n_parts, p.W), lds_count = sizeof(uint32_t) * (24u * 256u + (size_t)n_parts);
+  if (lds_place > PART_LDS_LIMIT) return set_error(MNT753_EINVAL, "msm_sort_partition: plan does not fit the LDS staging");
+  {
+    static bool lds_set = false;   // the placing pass stages its block's pairs in up to 160 KB of dynamic LDS (the attribute is per kernel)
+    if (!lds_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_pass<MOD_A, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_pass<MOD_B, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT));
+      lds_set = true;
+    }
+  }
+#define MNT753_PART_PASS(FRM, PLACE) hipLaunchKernelGGL((k_part_pass<FRM, PLACE>), dim3(gb), dim3(256), (PLACE) ? lds_place : lds_count, st, d_scal, d_inf, n, p.c, p.W, hs, entry_stride, entry_base, \
+                                                        n_parts, part_total, part_cursor, keys_out, vals_out)
+  if (frm == MOD_A) MNT753_PART_PASS(MOD_A, false); else MNT753_PART_PASS(MOD_B, false);
+  hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, part_cursor, n_parts);
+  if (frm == MOD_A) MNT753_PART_PASS(MOD_A, true); else MNT753_PART_PASS(MOD_B, true);
+#undef MNT753_PART_PASS
+  const unsigned gc = (unsigned)((total + SORT_CHUNK - 1) / SORT_CHUNK);   // worst case: every digit non-zero
+  hipLaunchKernelGGL((k_bucket_pass<false>), dim3(gc), dim3(1024), 0, st, keys_out, vals_out, part_start, n_parts, d_hist, d_offsets, d_sorted, pshift);
+  const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(SCAN_THREADS), 0, st, d_hist, d_offsets, d_blocksums, (size_t)p.n_buckets, pshift);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, d_blocksums, (size_t)nsb, d_total);
+  hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, d_offsets, d_cursor, d_blocksums, d_total, (size_t)p.n_buckets);
+  HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));   // now: entries placed per bucket
+  hipLaunchKernelGGL((k_bucket_pass<true>), dim3(gc), dim3(1024), 0, st, keys_out, vals_out, part_start, n_parts, d_hist, d_offsets, d_sorted, pshift);
+  if (pshift) hipLaunchKernelGGL(k_bucket_pad, dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, d_hist, d_offsets, d_sorted, pshift, p.n_buckets);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+size_t msm_sort_partition_ws_words() { return 3 * (PART_MAX + 1); }
+bool msm_sort_partition_fits(uint32_t n_buckets, int W) {
+  const uint32_t n_parts = (n_buckets + PART_BUCKETS - 1u) >> PART_BITS;
+  return n_parts <= PART_MAX && part_place_lds(n_parts, W) <= PART_LDS_LIMIT;
 }
 }  // namespace mnt753

@@ -38,6 +38,7 @@ struct mnt753_bases {
   uint32_t *d_keys_out = nullptr, *d_vals_out = nullptr, *d_dense = nullptr;
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
+  uint32_t* d_part_ws = nullptr;   // partition totals / starts / cursors of the two-level counting sort (msm_sort_partition)
   uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr, *d_edge_tmp = nullptr, *d_edge_flags = nullptr;
   uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;
   // pairing levels (batched affine additions ahead of the accumulate): grow-only buffers

@@ -289,11 +289,13 @@ def test_pairing_pass_cancellations_every_group(gpu, curve, group, monkeypatch):
     assert not got.any()
 
 
+@pytest.mark.parametrize("sort", ["part", "radix"])
 @pytest.mark.parametrize("group,logn", [(1, 19), (2, 17)])
-def test_skewed_scalars_with_the_pairing_pass(gpu, group, logn):
-    """The same three skewed scalar vectors at sizes where the pairing pass runs by default (G1 2^19, G2 2^17): a handful of
+def test_skewed_scalars_with_the_pairing_pass(gpu, group, logn, sort, monkeypatch):
+    """Both device-wide sort stages (the hand-written two-level counting sort, rocPRIM's radix sort).  The same three skewed scalar vectors at sizes where the pairing pass runs by default (G1 2^19, G2 2^17): a handful of
     giant buckets, thousands of empty ones between them (bisecting bucket walks), a sparse vector whose slot count is a
     fraction of the worst case (batch length derived on the device).  Exact through the discrete logs, and bounded."""
+    monkeypatch.setenv("MNT753_MSM_SORT", sort)
     n = 1 << logn
     pts = gpu.synth_points(0, group, 93, n)
     rnd = gpu.synth_scalars(0, 94, n)

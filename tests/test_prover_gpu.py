@@ -30,7 +30,8 @@ def test_reference_proof_files(gpu, curve, flags, tmp_path):
 
 @pytest.mark.parametrize("curve", [0, 1])
 @pytest.mark.parametrize("env", [{"MNT753_REDUCE_PAIR": "0"}, {"MNT753_REDUCE_LINE": "0"}, {"MNT753_REDUCE_PAIR": "0", "MNT753_REDUCE_LINE": "0"},
-                                 {"MNT753_REDUCE_PAIR_MAX": "100000000"}, {"MNT753_MSM_SORT": "atomic"}])
+                                 {"MNT753_REDUCE_PAIR_MAX": "100000000"}, {"MNT753_MSM_SORT": "atomic"}, {"MNT753_MSM_SORT": "radix"}, {"MNT753_MSM_SORT": "part"},
+                                 {"MNT753_MSM_SORT": "part", "MNT753_MSM_PAIR": "2"}, {"MNT753_EDGE_PAIR": "0"}])
 def test_alternative_kernel_paths_write_the_same_proof(gpu, curve, env, tmp_path):
     """The bucket reduction has three addition kernels (the VM's, two lanes per addition, straight-line) and the sort stage two
     variants; the environment switches between them and every combination must reproduce the reference's proof bytes."""

@@ -14,7 +14,7 @@ con = sqlite3.connect(dbs[0]); cur = con.cursor()
 t = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
 kd = [x for x in t if "kernel_dispatch" in x][0]; ks = [x for x in t if "kernel_symbol" in x][0]
 agg = collections.defaultdict(list)
-for n, dt in cur.execute(f"select s.display_name, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id"): agg[n.split("(")[0].replace("void mnt753::", "")].append(dt)
+for n, dt in cur.execute(f"select s.display_name, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id"): agg[n.replace("(anonymous namespace)::", "").split("(")[0].replace("void mnt753::", "").replace("void ", "")].append(dt)
 total = sum(sum(v) for v in agg.values()) or 1
 with open(f"{O}/{tag}_stats.csv", "w", newline="") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
