@@ -5,7 +5,7 @@
 // every XCD updates, executed at the memory side at ~20 G atomics/s: 1.9 ms, plus 1.3 ms for the scatter that re-reads digits and
 // ranks.  Two device-wide stages live here, both without an atomic per entry:
 //   * msm_sort_partition (round 3, the default): a hand-written two-level counting sort with the Booth-digit extraction and the
-//     slot-tree padding fused in -- 1.10-1.19 ms at 2^20 G1 points, see the comment above its kernels;
+//     slot-tree padding fused in -- 0.92 ms at 2^20 G1 points, see the comment above its kernels;
 //   * msm_sort_radix (round 2, MNT753_MSM_SORT=radix): k_scalar_keys writes (key = bucket, value = row | sign) pairs (zero digits get
 //     the sentinel key n_buckets and sort to the end), rocprim::radix_sort_pairs orders them (39.8 M pairs, 20 key bits), k_bucket_bounds
 //     finds every bucket's start by bisection, the usual scan turns the counts into padded offsets, k_expand copies the values to
@@ -13,6 +13,7 @@
 // The order of the entries inside a bucket differs between the stages; the MSM result is a sum and does not depend on it.
 // Group-independent, hence its own translation unit (rocPRIM is not pulled into the four point-arithmetic units).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -91,8 +92,9 @@ __global__ void __launch_bounds__(256) k_expand(const uint32_t* __restrict__ key
 //            a skewed digit distribution -- all scalars equal, half of them one -- costs no more than a uniform one).
 //            k_bucket_count: LDS histogram over the 1024 buckets of a spanned partition, flushed to the global bucket histogram (one
 //            atomic per chunk and non-empty bucket); the usual scan turns it into padded offsets (k_scan_blocks / _sums / _finish);
-//            k_bucket_place: counts again, reserves per bucket, writes the entries to their padded positions; k_bucket_pad writes the
-//            ENTRY_EMPTY padding of every bucket's last group (no 160 MB memset).
+//            k_bucket_place_staged: counts again, reserves per bucket, orders the chunk's entries by bucket in LDS and writes them to their
+//            padded positions (k_bucket_pass<true> is the unstaged form, MNT753_SORT_STAGED=0); k_bucket_pad writes the ENTRY_EMPTY
+//            padding of every bucket's last group (no 160 MB memset).
 constexpr uint32_t PART_BITS = 10, PART_BUCKETS = 1u << PART_BITS, PART_MAX = 4096, SORT_CHUNK = 8192;
 
 template <int FRM>
@@ -262,6 +264,57 @@ __global__ void __launch_bounds__(1024) k_bucket_pass(const uint32_t* __restrict
     __syncthreads();
   }
 }
+// The placing pass of level 2 with its entries ordered by bucket in LDS first: chunks of 16384 pairs, so that a bucket receives ~16
+// consecutive entries (64 B) from one chunk instead of single 4-byte writes (k_bucket_pass<true>: 0.54 ms for 159 MB).
+constexpr uint32_t PLACE_CHUNK = 16384;
+constexpr size_t PLACE_LDS = sizeof(uint32_t) * (3u * PART_BUCKETS + PLACE_CHUNK) + sizeof(uint16_t) * PLACE_CHUNK;
+__global__ void __launch_bounds__(1024) k_bucket_place_staged(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ part_start,
+                                                             uint32_t n_parts, uint32_t* __restrict__ placed, const uint32_t* __restrict__ offsets,
+                                                             uint32_t* __restrict__ sorted, uint32_t shift) {
+  extern __shared__ uint32_t place_lds[];
+  uint32_t* cnt = place_lds;                     // [1024]
+  uint32_t* lstart = cnt + PART_BUCKETS;         // [1024]
+  uint32_t* base = lstart + PART_BUCKETS;        // [1024]
+  uint32_t* st_v = base + PART_BUCKETS;          // [PLACE_CHUNK]
+  uint16_t* st_b = reinterpret_cast<uint16_t*>(st_v + PLACE_CHUNK);
+  const uint32_t total = part_start[n_parts];
+  const uint32_t lo = blockIdx.x * PLACE_CHUNK;
+  if (lo >= total) return;
+  const uint32_t hi = min(lo + PLACE_CHUNK, total);
+  uint32_t a = 0, b = n_parts - 1u;
+  while (a < b) { const uint32_t mid = (a + b + 1u) >> 1; if (part_start[mid] <= lo) a = mid; else b = mid - 1u; }
+  const uint32_t t = threadIdx.x;               // 1024 threads = one per bucket of a partition
+  for (uint32_t p = a; p < n_parts; ++p) {
+    const uint32_t ps = part_start[p], pe = part_start[p + 1];
+    if (ps >= hi) break;
+    const uint32_t s = max(ps, lo), e = min(pe, hi);
+    if (s >= e) continue;
+    const uint32_t b0 = p << PART_BITS;
+    cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t k = s + t; k < e; k += 1024) atomicAdd(&cnt[keys[k] - b0], 1u);
+    __syncthreads();
+    const uint32_t v = cnt[t];
+    uint32_t seg_total;
+    const uint32_t ex = block_exclusive_scan(v, &seg_total);   // (1024 threads; ends with a barrier)
+    lstart[t] = ex;
+    base[t] = v ? (offsets[b0 + t] << shift) + atomicAdd(&placed[b0 + t], v) : 0u;
+    cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t k = s + t; k < e; k += 1024) {
+      const uint32_t kb = keys[k] - b0;
+      const uint32_t j = lstart[kb] + atomicAdd(&cnt[kb], 1u);
+      st_v[j] = vals[k];
+      st_b[j] = (uint16_t)kb;
+    }
+    __syncthreads();
+    for (uint32_t j = t; j < e - s; j += 1024) {
+      const uint32_t kb = st_b[j];
+      sorted[base[kb] + (j - lstart[kb])] = st_v[j];
+    }
+    __syncthreads();
+  }
+}
 // the unused tail of every bucket's last group of 2^shift entries
 __global__ void __launch_bounds__(256) k_bucket_pad(const uint32_t* __restrict__ placed, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted, uint32_t shift,
                                                    uint32_t n_buckets) {
@@ -343,7 +396,15 @@ int msm_sort_partition(int frm, const uint32_t* d_scal, const uint8_t* d_inf, si
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, d_blocksums, (size_t)nsb, d_total);
   hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, d_offsets, d_cursor, d_blocksums, d_total, (size_t)p.n_buckets);
   HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));   // now: entries placed per bucket
-  hipLaunchKernelGGL((k_bucket_pass<true>), dim3(gc), dim3(1024), 0, st, keys_out, vals_out, part_start, n_parts, d_hist, d_offsets, d_sorted, pshift);
+  static const bool staged = !(getenv("MNT753_SORT_STAGED") && atoi(getenv("MNT753_SORT_STAGED")) == 0);
+  if (staged) {
+    static bool lds2 = false;
+    if (!lds2) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_place_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLACE_LDS)); lds2 = true; }
+    hipLaunchKernelGGL(k_bucket_place_staged, dim3((unsigned)((total + PLACE_CHUNK - 1) / PLACE_CHUNK)), dim3(1024), PLACE_LDS, st, keys_out, vals_out, part_start, n_parts,
+                       d_hist, d_offsets, d_sorted, pshift);
+  } else {
+    hipLaunchKernelGGL((k_bucket_pass<true>), dim3(gc), dim3(1024), 0, st, keys_out, vals_out, part_start, n_parts, d_hist, d_offsets, d_sorted, pshift);
+  }
   if (pshift) hipLaunchKernelGGL(k_bucket_pad, dim3((p.n_buckets + 255) / 256), dim3(256), 0, st, d_hist, d_offsets, d_sorted, pshift, p.n_buckets);
   HIP_TRY(hipGetLastError());
   return 0;
