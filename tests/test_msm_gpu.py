@@ -38,8 +38,12 @@ def test_vs_oracle_seeded(gpu, curve, group, n):
     assert np.array_equal(gpu_msm_affine(gpu, curve, group, pts, sc), O.msm(curve, group, pts, sc, chunks=3))
 
 
+@pytest.mark.parametrize("sort", ["atomic", "part", "radix"])
 @pytest.mark.parametrize("curve,group", GROUPS)
-def test_edge_cases(gpu, curve, group):
+def test_edge_cases(gpu, curve, group, sort, monkeypatch):
+    """Every sort stage (the counting sort with atomics that small inputs take by default, the hand-written two-level counting sort and
+    the rocPRIM stage, both forced onto this small input): empty list, no entries at all, one giant bucket per window, offsets."""
+    monkeypatch.setenv("MNT753_MSM_SORT", sort)
     n = 96
     pts = gpu.synth_points(curve, group, 31, n)
     sc = gpu.synth_scalars(curve, 32, n)
@@ -64,8 +68,11 @@ def test_edge_cases(gpu, curve, group):
     assert np.array_equal(gpu_msm_affine(gpu, curve, group, allinf, sc), zero_aff)
 
 
+@pytest.mark.parametrize("sort", ["atomic", "part"])
 @pytest.mark.parametrize("c", [3, 7, 11, 16])
-def test_window_size_does_not_change_the_result(gpu, c):
+def test_window_size_does_not_change_the_result(gpu, c, sort, monkeypatch):
+    """(table-less mode: one bucket set per window; c = 16 gives 48 x 2^15 buckets = 1536 partitions for the two-level sort)"""
+    monkeypatch.setenv("MNT753_MSM_SORT", sort)
     n = 300
     pts = gpu.synth_points(0, 1, 41, n); sc = gpu.synth_scalars(0, 42, n)
     expect = O.msm(0, 1, pts, sc)
