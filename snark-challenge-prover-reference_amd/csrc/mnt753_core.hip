@@ -4,8 +4,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "common_host.hpp"
 #include "host_field.hpp"
@@ -13,14 +19,20 @@
 namespace mnt753 {
 namespace {
 thread_local std::string t_last_error;
-// persistent staging for mnt753_load_file_to_device: creating a stream costs ~8 ms and pinning 32 MB a few more, so
-// they are made once per device at initialisation (outside any timed region) and reused under a mutex
-struct IoStaging {
-  static constexpr size_t CHUNK = (size_t)16 << 20;
-  std::mutex mu;
+// persistent staging for mnt753_load_file_to_device: creating a stream costs ~8 ms and pinning memory a few more, so they are made
+// once per device at initialisation (outside any timed region) and reused under a mutex.  IO_LANES independent lanes (a stream, two
+// pinned 8 MB buffers and their events each): a large read is cut into IO_LANES contiguous parts that are read (pread) and copied
+// concurrently (opt-in, see mnt753_load_file_to_device).
+constexpr int IO_LANES = 4;
+struct IoLane {
   hipStream_t stream = nullptr;
   void* buf[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
+};
+struct IoStaging {
+  static constexpr size_t CHUNK = (size_t)8 << 20;
+  std::mutex mu;
+  IoLane lane[IO_LANES];
   bool ok = false;
 };
 // Logical devices 0 .. g_ndev-1 of this process.  mnt753_init(d) makes physical device d logical device 0 (the single-GPU
@@ -60,9 +72,26 @@ int init_one(int logical, int phys) {
   DevState& d = g_devs[logical];
   d.phys = phys;
   if (!d.io.ok) {
-    bool ok = hipStreamCreateWithFlags(&d.io.stream, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 2 && ok; ++k)
-      ok = hipHostMalloc(&d.io.buf[k], IoStaging::CHUNK) == hipSuccess && hipEventCreateWithFlags(&d.io.done[k], hipEventDisableTiming) == hipSuccess;
+    bool ok = true;
+    for (int l = 0; l < IO_LANES && ok; ++l) {
+      ok = hipStreamCreateWithFlags(&d.io.lane[l].stream, hipStreamNonBlocking) == hipSuccess;
+      for (int k = 0; k < 2 && ok; ++k) {
+        ok = hipHostMalloc(&d.io.lane[l].buf[k], IoStaging::CHUNK) == hipSuccess && hipEventCreateWithFlags(&d.io.lane[l].done[k], hipEventDisableTiming) == hipSuccess;
+        // touch every page now: the first proof of a process otherwise pays the page faults of 64 MB of pinned memory inside its
+        // timed window (measured: first input load 24-32 ms, later ones 9-13 ms)
+        if (ok) memset(d.io.lane[l].buf[k], 0, IoStaging::CHUNK);
+      }
+    }
+    // first use of a stream creates its hardware queue (milliseconds): one small copy per lane now, not inside the first proof
+    if (ok) {
+      void* scratch = nullptr;
+      if (hipMalloc(&scratch, 4096) == hipSuccess) {
+        for (int l = 0; l < IO_LANES; ++l) (void)hipMemcpyAsync(scratch, d.io.lane[l].buf[0], 4096, hipMemcpyHostToDevice, d.io.lane[l].stream);
+        for (int l = 0; l < IO_LANES; ++l) (void)hipStreamSynchronize(d.io.lane[l].stream);
+        (void)hipFree(scratch);
+      }
+      (void)hipGetLastError();
+    }
     d.io.ok = ok;
   }
   d.ready = true;
@@ -272,27 +301,63 @@ int mnt753_load_file_to_device(const char* path, size_t file_offset, size_t byte
   if (int rc = require_device()) return rc;
   if (!path || (bytes && !dev_dst)) return set_error(MNT753_EINVAL, "load_file_to_device: null argument");
   IoStaging& g_io = g_devs[t_cur_dev < g_ndev ? t_cur_dev : 0].io;
-  HIP_TRY(hipSetDevice(current_physical_device()));   // may be called from a thread that has not touched the device yet
-  FILE* f = fopen(path, "rb");
-  if (!f) return set_error(MNT753_EINVAL, "load_file_to_device: cannot open file");
-  if (fseeko(f, (off_t)file_offset, SEEK_SET) != 0) { fclose(f); return set_error(MNT753_EINVAL, "load_file_to_device: seek failed"); }
-  std::lock_guard<std::mutex> lock(g_io.mu);
-  if (!g_io.ok) { fclose(f); return set_error(MNT753_EHIP, "load_file_to_device: staging buffers were not created by mnt753_init"); }
-  constexpr size_t CHUNK = IoStaging::CHUNK;
-  int rc = 0;
-  size_t off = 0;
-  for (size_t i = 0; off < bytes; ++i) {
-    const int k = (int)(i & 1);
-    const size_t n = bytes - off < CHUNK ? bytes - off : CHUNK;
-    if (i >= 2 && hipEventSynchronize(g_io.done[k]) != hipSuccess) { rc = set_error(MNT753_EHIP, "load_file_to_device: event"); break; }
-    if (fread(g_io.buf[k], 1, n, f) != n) { rc = set_error(MNT753_EINVAL, "load_file_to_device: short read"); break; }
-    if (hipMemcpyAsync((char*)dev_dst + off, g_io.buf[k], n, hipMemcpyHostToDevice, g_io.stream) != hipSuccess ||
-        hipEventRecord(g_io.done[k], g_io.stream) != hipSuccess) { rc = set_error(MNT753_EHIP, "load_file_to_device: copy"); break; }
-    off += n;
+  const int phys = current_physical_device();
+  HIP_TRY(hipSetDevice(phys));   // may be called from a thread that has not touched the device yet
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return set_error(MNT753_EINVAL, "load_file_to_device: cannot open file");
+  struct stat fst;
+  if (fstat(fd, &fst) != 0 || (unsigned long long)fst.st_size < (unsigned long long)file_offset + bytes) {
+    close(fd);
+    return set_error(MNT753_EINVAL, "load_file_to_device: short read");
   }
-  if (hipStreamSynchronize(g_io.stream) != hipSuccess && rc == 0) rc = set_error(MNT753_EHIP, "load_file_to_device: sync");
-  fclose(f);
-  return rc;
+  std::lock_guard<std::mutex> lock(g_io.mu);
+  if (!g_io.ok) { close(fd); return set_error(MNT753_EHIP, "load_file_to_device: staging buffers were not created by mnt753_init"); }
+  constexpr size_t CHUNK = IoStaging::CHUNK;
+  // one lane's share: chunks of CHUNK, the pread of chunk i + 1 overlaps the H2D copy of chunk i; 0 = fine, 1 = read error, 2 = HIP error
+  auto run_lane = [&](int l, size_t lo, size_t hi) -> int {
+    IoLane& L = g_io.lane[l];
+    if (hipSetDevice(phys) != hipSuccess) return 2;
+    int rc = 0;
+    size_t off = lo;
+    for (size_t i = 0; off < hi; ++i) {
+      const int k = (int)(i & 1);
+      const size_t n = hi - off < CHUNK ? hi - off : CHUNK;
+      if (i >= 2 && hipEventSynchronize(L.done[k]) != hipSuccess) { rc = 2; break; }
+      size_t got = 0;
+      while (got < n) {
+        const ssize_t r = pread(fd, (char*)L.buf[k] + got, n - got, (off_t)(file_offset + off + got));
+        if (r <= 0) break;
+        got += (size_t)r;
+      }
+      if (got != n) { rc = 1; break; }
+      if (hipMemcpyAsync((char*)dev_dst + off, L.buf[k], n, hipMemcpyHostToDevice, L.stream) != hipSuccess || hipEventRecord(L.done[k], L.stream) != hipSuccess) { rc = 2; break; }
+      off += n;
+    }
+    if (hipStreamSynchronize(L.stream) != hipSuccess && rc == 0) rc = 2;
+    return rc;
+  };
+  // small reads stay on one lane; large ones are cut into IO_LANES contiguous parts (multiples of CHUNK)
+  // Default ONE lane: what made the loader twice as fast in round 3 was pread straight into the pinned buffer instead of fread through
+  // a stdio buffer (403 MB: 21 -> 12 ms).  More lanes bring a resident prover to 9-10 ms and 0.180 instead of 0.182 s per proof, but
+  // the FIRST proof of a process -- the reference's metric -- pays their thread and queue start-up (0.187-0.195 s), so they are
+  // opt-in (MNT753_IO_LANES=2..4; profiles/r03/prove_io_lanes.txt).
+  static const int max_lanes = [] { const char* e = getenv("MNT753_IO_LANES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > IO_LANES ? IO_LANES : v); }();
+  const int lanes = bytes >= 4 * CHUNK ? max_lanes : 1;
+  const size_t per = ((bytes / (size_t)lanes + CHUNK - 1) / CHUNK) * CHUNK;
+  int rcs[IO_LANES] = {0, 0, 0, 0};
+  std::thread workers[IO_LANES];
+  for (int l = 1; l < lanes; ++l) {
+    const size_t lo = std::min(bytes, (size_t)l * per), hi = std::min(bytes, (size_t)(l + 1) * per);
+    workers[l] = std::thread([&, l, lo, hi]() { rcs[l] = run_lane(l, lo, hi); });
+  }
+  rcs[0] = run_lane(0, 0, std::min(bytes, per));
+  for (int l = 1; l < lanes; ++l) workers[l].join();
+  close(fd);
+  for (int l = 0; l < lanes; ++l) {
+    if (rcs[l] == 1) return set_error(MNT753_EINVAL, "load_file_to_device: short read");
+    if (rcs[l] == 2) return set_error(MNT753_EHIP, "load_file_to_device: copy");
+  }
+  return 0;
 }
 int mnt753_sync(void* stream) {
   if (int rc = require_device()) return rc;
