@@ -375,14 +375,10 @@ int msm_sort_partition(int frm, const uint32_t* d_scal, const uint8_t* d_inf, si
   HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
   const size_t lds_place = part_place_lds(n_parts, p.W), lds_count = sizeof(uint32_t) * (24u * 256u + (size_t)n_parts);
   if (lds_place > PART_LDS_LIMIT) return set_error(MNT753_EINVAL, "msm_sort_partition: plan does not fit the LDS staging");
-  {
-    static bool lds_set = false;   // the placing pass stages its block's pairs in up to 160 KB of dynamic LDS (the attribute is per kernel)
-    if (!lds_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_pass<MOD_A, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_pass<MOD_B, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT));
-      lds_set = true;
-    }
-  }
+  // the placing passes stage their pairs in up to 160 KB of dynamic LDS: the opt-in is per kernel AND device, the call costs
+  // microseconds, so it is simply repeated on whatever device this MSM runs on
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(frm == MOD_A ? (const void*)&k_part_pass<MOD_A, true> : (const void*)&k_part_pass<MOD_B, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT));
 #define MNT753_PART_PASS(FRM, PLACE) hipLaunchKernelGGL((k_part_pass<FRM, PLACE>), dim3(gb), dim3(256), (PLACE) ? lds_place : lds_count, st, d_scal, d_inf, n, p.c, p.W, hs, entry_stride, entry_base, \
                                                         n_parts, part_total, part_cursor, keys_out, vals_out)
   if (frm == MOD_A) MNT753_PART_PASS(MOD_A, false); else MNT753_PART_PASS(MOD_B, false);
@@ -398,8 +394,7 @@ int msm_sort_partition(int frm, const uint32_t* d_scal, const uint8_t* d_inf, si
   HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));   // now: entries placed per bucket
   static const bool staged = !(getenv("MNT753_SORT_STAGED") && atoi(getenv("MNT753_SORT_STAGED")) == 0);
   if (staged) {
-    static bool lds2 = false;
-    if (!lds2) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_place_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLACE_LDS)); lds2 = true; }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_place_staged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLACE_LDS));
     hipLaunchKernelGGL(k_bucket_place_staged, dim3((unsigned)((total + PLACE_CHUNK - 1) / PLACE_CHUNK)), dim3(1024), PLACE_LDS, st, keys_out, vals_out, part_start, n_parts,
                        d_hist, d_offsets, d_sorted, pshift);
   } else {

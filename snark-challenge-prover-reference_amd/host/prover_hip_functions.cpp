@@ -229,6 +229,7 @@ public:
     const int n_dev = std::max(1, mnt753_device_count());
     if (n_dev < 2) return;
     w_slices = std::make_shared<std::vector<DevSlice>>((size_t)n_dev);
+    struct BackToDevice0 { ~BackToDevice0() { (void)mnt753_set_device(0); } } back;   // also when an allocation throws
     for (int g = 1; g < n_dev; ++g) {
       size_t lo_a, hi_a, lo_l, hi_l;
       slice_bounds(m + 1, n_dev, g, &lo_a, &hi_a);   // A, B1, B2: scalars w[lo .. hi)
@@ -486,9 +487,9 @@ static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarS
         sc = reinterpret_cast<const uint64_t*>(sl->buf->ptr) + 12 * (src.offset + lo - sl->first);
       } else {
         if (!part.scalars || part.scalars->bytes < 96 * (hi - lo)) {
+          struct BackToDevice0 { ~BackToDevice0() { (void)mnt753_set_device(0); } } back;   // also when the allocation throws
           check(mnt753_set_device(g), "mnt753_set_device");
           part.scalars = std::make_shared<DeviceBuffer>(96 * (part.hi - part.lo));
-          check(mnt753_set_device(0), "mnt753_set_device");
         }
         check(mnt753_copy_peer_async(g, part.scalars->ptr, 0, src.dev0() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
         sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
