@@ -66,6 +66,7 @@ int mnt753_init(int device);
 int mnt753_init_devices(int n_devices);
 int mnt753_device_count(void);
 int mnt753_set_device(int logical_device);
+int mnt753_get_device(void);   /* the calling thread's current logical device (0 before mnt753_set_device) */
 int mnt753_copy_peer(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes);
 /* The same without blocking the host: the copy is enqueued on dst_device's default stream and starts after everything enqueued so
  * far on src_device's default stream (an event recorded there, waited for on the destination) -- how the slices of

@@ -38,6 +38,7 @@ def lib():
         "mnt753_init_devices": (i, [i]),
         "mnt753_device_count": (i, []),
         "mnt753_set_device": (i, [i]),
+        "mnt753_get_device": (i, []),
         "mnt753_copy_peer": (i, [i, vp, i, vp, sz]),
         "mnt753_copy_peer_async": (i, [i, vp, i, vp, sz]),
         "mnt753_last_error": (C.c_char_p, []),

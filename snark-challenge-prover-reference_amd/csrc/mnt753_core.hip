@@ -217,6 +217,8 @@ int mnt753_set_device(int logical) {
   return 0;
 }
 
+int mnt753_get_device(void) { return t_cur_dev < g_ndev ? t_cur_dev : 0; }
+
 int mnt753_copy_peer(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes) {
   if (dst_device < 0 || dst_device >= g_ndev || src_device < 0 || src_device >= g_ndev) return set_error(MNT753_EINVAL, "copy_peer: bad device");
   if (bytes && (!dev_dst || !dev_src)) return set_error(MNT753_EINVAL, "copy_peer: null");

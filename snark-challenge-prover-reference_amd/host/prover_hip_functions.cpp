@@ -28,11 +28,48 @@ namespace mnt753_hip_detail {
 }
 static void check(int rc, const char* what) { if (rc != 0) fail(what); }
 
+// Per-proof vectors (w, ca, cb, cc, coefficients_for_H, the per-device slices) have the same sizes proof after proof, and both
+// hipMalloc and hipFree are expensive where it hurts: four 100 MB hipMallocs open the reference's timing window (1 ms on an idle box,
+// 9 ms measured on a loaded one) and every hipFree is a device-wide synchronisation.  Freed blocks are therefore kept, per
+// (device, size), and handed to the next buffer of that size; B::read_params pre-allocates the set of a proof so that the first proof
+// finds them too; B::delete_groth16_params gives everything back.
+struct BufferCache {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void*> blocks;
+  size_t held = 0;
+  static constexpr size_t LIMIT = (size_t)4 << 30;   // bytes kept per process
+  void* take(int dev, size_t n) {
+    std::lock_guard<std::mutex> l(mu);
+    auto it = blocks.find({dev, n});
+    if (it == blocks.end()) return nullptr;
+    void* p = it->second;
+    blocks.erase(it);
+    held -= n;
+    return p;
+  }
+  bool give(int dev, size_t n, void* p) {
+    std::lock_guard<std::mutex> l(mu);
+    if (held + n > LIMIT) return false;
+    blocks.insert({{dev, n}, p});
+    held += n;
+    return true;
+  }
+  void release_all() {
+    std::multimap<std::pair<int, size_t>, void*> all;
+    { std::lock_guard<std::mutex> l(mu); all.swap(blocks); held = 0; }
+    for (auto& kv : all) mnt753_dev_free(kv.second);
+  }
+};
+static BufferCache g_buffers;
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t bytes = 0;
-  explicit DeviceBuffer(size_t n) : bytes(n) { check(mnt753_dev_alloc(&ptr, n), "mnt753_dev_alloc"); }
-  ~DeviceBuffer() { if (ptr) mnt753_dev_free(ptr); }
+  int device = 0;   // logical device the block lives on (the calling thread's current one)
+  explicit DeviceBuffer(size_t n) : bytes(n), device(mnt753_get_device()) {
+    ptr = g_buffers.take(device, n);
+    if (!ptr) check(mnt753_dev_alloc(&ptr, n), "mnt753_dev_alloc");
+  }
+  ~DeviceBuffer() { if (ptr && !g_buffers.give(device, bytes, ptr)) mnt753_dev_free(ptr); }
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
 };
@@ -555,8 +592,16 @@ template <int CURVE> static void warm_up(typename mnt753_hip_impl<CURVE>::groth1
 }
 template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const char* path) {
   groth16_params* p = new groth16_params(path);
-  (void)cached_domain<CURVE>(p->d + 1);
+  auto dom = cached_domain<CURVE>(p->d + 1);
   warm_up<CURVE>(p);
+  // the buffers of one proof, allocated now and parked in the cache: w, ca, cb, cc, coefficients_for_H (device 0)
+  {
+    const size_t m_dom = mnt753_domain_size(dom->h);
+    std::vector<std::unique_ptr<DeviceBuffer>> pre;
+    pre.emplace_back(new DeviceBuffer(96 * (p->m + 1)));
+    for (int k = 0; k < 3; ++k) pre.emplace_back(new DeviceBuffer(96 * (p->d + 1)));
+    pre.emplace_back(new DeviceBuffer(96 * (m_dom + 1)));
+  }
   return p;
 }
 template <int CURVE> size_t HIP_B::params_d(groth16_params* p) { return p->d; }
@@ -574,7 +619,7 @@ template <int CURVE> void HIP_B::delete_vector_Fr(vector_Fr* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_G1(vector_G1* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_G2(vector_G2* a) { delete a; }
 template <int CURVE> void HIP_B::delete_groth16_input(groth16_input* a) { delete a; }
-template <int CURVE> void HIP_B::delete_groth16_params(groth16_params* a) { delete a; }
+template <int CURVE> void HIP_B::delete_groth16_params(groth16_params* a) { delete a; g_buffers.release_all(); }
 template <int CURVE> void HIP_B::delete_evaluation_domain(evaluation_domain* a) { delete a; }
 
 // write_g1(A) write_g2(B) write_g1(C)   (prover_reference_functions.cpp:347-356, serialization.hpp:44-67)

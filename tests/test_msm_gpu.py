@@ -336,3 +336,41 @@ def test_pairing_pass_thousands_of_cancellations_in_one_bucket(gpu, monkeypatch)
     got = gpu_msm_affine(gpu, 0, 1, pts, sc)
     assert np.array_equal(got, want)
     assert gpu.msm_last_timing()["total_ms"] < 500 or not os.environ.get("MNT753_TIMING_ASSERTS")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_configurations_vs_oracle(gpu, seed, monkeypatch):
+    """Differential test over the knobs that select code paths: group, size, window table on / off, pairing levels 0-3, batch floor,
+    sort stage, two-lane reduction / edge merge on / off, with the special values mixed into the scalars (0, 1, r - 1 as -1, repeated
+    scalars) and the bases (identity, duplicates, a point and its negative under one scalar).  Every combination must give the
+    oracle's (= libff's BDLO12) group element."""
+    rng = np.random.default_rng(1000 + seed)
+    curve, group = GROUPS[int(rng.integers(0, 4))]
+    n = int(rng.integers(1, 420 if group == 1 else 130))
+    env = {"MNT753_MSM_PRECOMP": str(int(rng.integers(0, 2))), "MNT753_MSM_PAIR": str(int(rng.integers(0, 4))),
+           "MNT753_PAIR_MINB": str(int(rng.choice([1, 2, 8, 48]))), "MNT753_MSM_SORT": str(rng.choice(["atomic", "part", "radix"])),
+           "MNT753_REDUCE_PAIR": str(int(rng.integers(0, 2))), "MNT753_EDGE_PAIR": str(int(rng.integers(0, 2))),
+           "MNT753_REDUCE_LINE": str(int(rng.integers(0, 2)))}
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pts = gpu.synth_points(curve, group, 7000 + seed, n)
+    sc = gpu.synth_scalars(curve, 8000 + seed, n)
+    one = gpu.api.mont_one(curve)
+    for _ in range(max(1, n // 8)):
+        i, j = (int(x) for x in rng.integers(0, n, size=2))
+        kind = int(rng.integers(0, 6))
+        if kind == 0: sc[i] = 0
+        elif kind == 1: sc[i] = one
+        elif kind == 2: sc[i] = O.field_op(curve, 5, one)                # -1 in Fr (modulus A = index 0 is Fr of MNT4753, B = 1 of MNT6753)
+        elif kind == 3: sc[i] = sc[j]
+        elif kind == 4: pts[i] = 0                                       # identity base
+        else: pts[i] = pts[j]; sc[i] = sc[j]                             # duplicate point under the same scalar (a doubling in its bucket)
+    if n >= 4:   # a point and its negative under one scalar: the pair cancels
+        aw = gpu.affine_words(curve, group) // 2
+        pts[1] = pts[0]
+        fq = 1 if curve == 0 else 0                                      # coordinate field: modulus B for MNT4753, A for MNT6753
+        neg = np.stack([O.field_op(fq, 5, pts[0][aw + 12 * k: aw + 12 * k + 12]) for k in range(aw // 12)]).reshape(-1)
+        pts[1][aw:] = neg
+        sc[1] = sc[0]
+    got = gpu_msm_affine(gpu, curve, group, pts, sc)
+    assert np.array_equal(got, O.msm(curve, group, pts, sc)), f"configuration {env} curve {curve} group {group} n {n}"

@@ -54,6 +54,7 @@ int mnt753_init(int device) { if (device != 0) return fail(MNT753_EINVAL, "stub:
 int mnt753_init_devices(int n) { if (n < 1 || n > 16) return fail(MNT753_EINVAL, "mnt753_init_devices: more devices requested than visible"); g_ndev = n; t_dev = 0; return 0; }
 int mnt753_device_count(void) { return g_ndev; }
 int mnt753_set_device(int d) { if (d < 0 || d >= g_ndev) return fail(MNT753_EINVAL, "mnt753_set_device: not an initialised device"); t_dev = d; return 0; }
+int mnt753_get_device(void) { return t_dev; }
 int mnt753_copy_peer(int, void* d, int, const void* s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int mnt753_copy_peer_async(int dd, void* d, int sd, const void* s, size_t n) { if (dd < 0 || dd >= g_ndev || sd < 0 || sd >= g_ndev) return fail(MNT753_EINVAL, "copy_peer_async: bad device"); if (n) memcpy(d, s, n); return 0; }
 const char* mnt753_last_error(void) { return t_err.c_str(); }
