@@ -159,6 +159,10 @@ int mnt753_divide_by_z_on_coset(mnt753_domain* d, uint64_t* dev_vec, void* strea
 /* replaces B::vector_Fr_muleq / vector_Fr_subeq (hpp:35-36): a[i] = a[i] (*|-) b[i], i < n */
 int mnt753_vec_muleq(int curve, uint64_t* dev_a, const uint64_t* dev_b, size_t n, void* stream);
 int mnt753_vec_subeq(int curve, uint64_t* dev_a, const uint64_t* dev_b, size_t n, void* stream);
+/* dst[i] = src[i] * k, i < n, k one Fr element in HOST memory (wire format); dst may be src.  Used to fold the factor r of
+ * r * Bt1 (cuda_prover_piecewise.cu:85-87: B::G1_scale(B::input_r(inputs), evaluation_Bt1)) into the scalars of that sum, so that
+ * Ht + Lt + r Bt1 becomes one multi-scalar multiplication (B::groth16_C, include/prover_hip_functions.hpp). */
+int mnt753_vec_scale(int curve, uint64_t* dev_dst, const uint64_t* dev_src, const uint64_t* host_scalar, size_t n, void* stream);
 /* the whole of compute_H (cuda_prover_piecewise.cu:18-53) resident on the device:
  * dev_ca / dev_cb / dev_cc hold m elements each and are overwritten; dev_h receives m + 1 elements
  * (coefficients_for_H, last entry 0). */

@@ -100,6 +100,12 @@ public:
   // ---- extensions (not in the reference wrapper) -------------------------------------------------
   // the whole of compute_H<B> in one device-resident call (overwrites ca, cb, cc like the reference)
   static vector_Fr *compute_H_fused(evaluation_domain *domain, vector_Fr *ca, vector_Fr *cb, vector_Fr *cc);
+  // C = Ht + Lt + r Bt1 (cuda_prover_piecewise.cu:79-90: three multiexps, B::G1_scale, two B::G1_add) as ONE multi-scalar
+  // multiplication over the concatenated base set H | L | B1 with the scalars coefficients_for_H | w_L | r w.  The same group
+  // element, hence the same proof bytes.  read_params builds the concatenated set (and B1 / L / H as sets of their own only when
+  // params_B1 / params_L / params_H are first asked for) unless fuse_C(false) was called before it or MNT753_FUSED_C=0 is set.
+  static G1 *groth16_C(groth16_params *params, vector_Fr *coefficients_for_H, vector_Fr *w_L, vector_Fr *w, field *r);
+  static void fuse_C(bool on);
   // Number of GPUs of this node the parameters are sharded over (call before init_public_params; default 1, or the value of
   // the environment variable MNT753_GPUS).  Every vector_G1 / vector_G2 is cut into contiguous slices, one per device, exactly
   // as libff cuts an MSM over OpenMP threads (multiexp.tcc:417-431); multiexp_G1 / multiexp_G2 run the slices concurrently

@@ -47,4 +47,5 @@ g++ $F $HERE/ref_msm_bench.cpp $O/obj/*.o -o $O/ref_msm_bench $GMP_SO & PIDS="$P
 # fixtures + checker for the steps either side of the hot path (witness map, full proof + verifier): OUR program on the reference's libsnark
 g++ $F $HERE/ref_groth16.cpp $O/obj/*.o -o $O/ref_groth16 $GMP_SO & PIDS="$PIDS $!"
 wait_all
+rm -f $O/piecewise_host.gen.cpp   # holds the reference's text: not kept once it is compiled
 echo "build_ref: built $(ls $O | tr '\n' ' ')"

@@ -2,19 +2,23 @@
 """prove_mgpu.py -- the whole Groth16 prove sharded over the GPUs of one node.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        prove_mgpu.py MNT4753|MNT6753 compute <params> <input> <output>
+        prove_mgpu.py MNT4753|MNT6753 compute <params> <input> <output> [--unfused-c]
     python prove_mgpu.py ...                      (N = 1)
 
 Same files and same proof bytes as `./main <curve> compute ...` of the reference and as the single-GPU `main_hip`.
 Decomposition = the reference's own OpenMP chunking of an MSM (multiexp.tcc:402-441) lifted to GPUs:
 
-  * rank g keeps the slice [lo_g, hi_g) of each of the five base vectors (A, B1, B2, L, H) resident in its HBM,
-    with its window table; parameter loading is outside the timed window (libsnark/main.cpp:201-203);
-  * every rank streams the (small) input to its GPU (w first, the four w-only MSMs start behind it) and runs compute_H itself -- the FFT is not sharded: 100 MB fit one GPU and a
-    distributed NTT would move the whole vector over xGMI for ~3 % of the work;
-  * the five local MSMs run concurrently on their base sets' streams (mnt753_msm_start / _finish);
-  * ONE all_gather per proof carries the five partial points of every rank (5 x 36..108 u64 -- latency bound);
-    every rank folds them in rank order, rank 0 finishes C = Ht + Lt + r*Bt1 and writes the proof.
+  * rank g keeps the slice [lo_g, hi_g) of A and of B2 resident in its HBM and, as ONE base set, its slices of H, L and B1
+    concatenated (C = Ht + Lt + r Bt1 is one group element: one MSM over H_g | L_g | B1_g with the scalars h | w_L | r w instead of
+    three MSMs, a scalar multiplication and two additions -- B::groth16_C of the single-process wrapper), each with its window
+    table; parameter loading is outside the timed window (libsnark/main.cpp:201-203).  --unfused-c keeps the five base sets and
+    the reference's five multiexps;
+  * every rank streams the (small) input to its GPU (w first, the MSMs that only need w start behind it) and runs compute_H
+    itself -- the FFT is not sharded: 100 MB fit one GPU and a distributed NTT would move the whole vector over xGMI for ~3 % of
+    the work;
+  * the local MSMs run concurrently on their base sets' streams (mnt753_msm_start / _finish);
+  * ONE all_gather per proof carries the three (five) partial points of every rank (36..108 u64 each -- latency bound);
+    every rank folds them in rank order, rank 0 writes the proof.
 
 PyTorch is plumbing: torch.distributed (backend nccl = RCCL) and nothing else.  PROVE_SHARE_GPU=1 (development) lets all
 ranks share GPU 0 over gloo so the flow can be exercised on a single-GPU box.
@@ -36,9 +40,10 @@ def read_slice(path, offset_bytes, n_rows, row_words):
 
 def main():
     if len(sys.argv) < 6 or sys.argv[2] != "compute":
-        raise SystemExit("usage: prove_mgpu.py MNT4753|MNT6753 compute <params> <input> <output>")
+        raise SystemExit("usage: prove_mgpu.py MNT4753|MNT6753 compute <params> <input> <output> [--unfused-c]")
     curve = {"MNT4753": 0, "MNT6753": 1}[sys.argv[1]]
     params_path, input_path, output_path = sys.argv[3:6]
+    fused = "--unfused-c" not in sys.argv[6:]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,12 +71,19 @@ def main():
     d, m = (int(v) for v in np.fromfile(params_path, dtype=np.uint64, count=2))
     # file layout: d, m, A[m+1] G1, B1[m+1] G1, B2[m+1] G2, L[m-1] G1, H[d] G1   (generate_parameters.cpp:60-85)
     layout = [("A", 1, g1w, m + 1), ("B1", 1, g1w, m + 1), ("B2", 2, g2w, m + 1), ("L", 1, g1w, m - 1), ("H", 1, g1w, d)]
-    sets, spans, off = {}, {}, 16
+    sets, spans, rows, off = {}, {}, {}, 16
     for name, group, words, n in layout:
         lo, hi = pkg.parallel.shard_range(n, rank, world)
-        sets[name] = pkg.BaseSet(curve, group, read_slice(params_path, off + lo * words * 8, hi - lo, words))
+        rows[name] = read_slice(params_path, off + lo * words * 8, hi - lo, words)
         spans[name] = (lo, hi)
         off += n * words * 8
+    if fused:
+        rows["C"] = np.concatenate([rows.pop("H"), rows.pop("L"), rows.pop("B1")])
+        results = [("A", 1), ("B2", 2), ("C", 1)]
+    else:
+        results = [(name, group) for name, group, _, _ in layout]
+    for name, group in results:
+        sets[name] = pkg.BaseSet(curve, group, rows.pop(name))
     dom = pkg.Domain(curve, d + 1)   # twiddle tables depend on the parameters only (like the window tables)
     if world > 1:
         dist.barrier()
@@ -79,8 +91,8 @@ def main():
 
     # ---- timed window: input load + compute + output write (main.cpp:203-270) ----
     # input file: w[m+1], ca[d+1], cb[d+1], cc[d+1], r   (generate_parameters.cpp:88-108).  Same data-driven order as
-    # host/main.cpp: w is streamed to the device first (mnt753_load_file_to_device), the four MSMs that only need w are
-    # enqueued -- the G2 one first --, ca / cb / cc arrive while they run, then compute_H and the H MSM.
+    # host/main.cpp: w is streamed to the device first (mnt753_load_file_to_device), the MSMs that only need w are
+    # enqueued -- the G2 one first --, ca / cb / cc arrive while they run, then compute_H and the MSM that needs its result.
     n_w, n_c = m + 1, d + 1
     d_w = pkg.DeviceBuffer.from_file(input_path, 0, 96 * n_w)
     d_h = pkg.DeviceBuffer(96 * (d + 2))
@@ -92,39 +104,52 @@ def main():
         lo, hi = spans[name]
         sets[name].msm_start(buf.ptr.value + 96 * (lo + shift), hi - lo)
 
-    for name in ("B2", "A", "B1", "L"):
+    for name in ("B2", "A") if fused else ("B2", "A", "B1", "L"):
         start(name)
     d_abc = [pkg.DeviceBuffer.from_file(input_path, 96 * n_w + k * 96 * n_c, 96 * n_c) for k in range(3)]
     r = np.fromfile(input_path, dtype=np.uint64, count=12, offset=96 * n_w + 3 * 96 * n_c)
     t_in = time.perf_counter()
     dom.compute_h(d_abc[0].ptr.value, d_abc[1].ptr.value, d_abc[2].ptr.value, d_h.ptr.value)
-    start("H")
-    partial = {name: sets[name].msm_finish() for name, _, _, _ in layout}
+    if fused:
+        # scalars of this rank's slice of the concatenated sum: h[lo_H, hi_H) | w[2 + lo_L, 2 + hi_L) | r * w[lo_B1, hi_B1)
+        (lh, hh), (ll, hl), (lb, hb) = spans["H"], spans["L"], spans["B1"]
+        n_c_set = (hh - lh) + (hl - ll) + (hb - lb)
+        d_sc = pkg.DeviceBuffer(96 * max(n_c_set, 1))
+        pkg.copy_d2d(d_sc.ptr.value, d_h.ptr.value + 96 * lh, 96 * (hh - lh))
+        pkg.copy_d2d(d_sc.ptr.value + 96 * (hh - lh), d_w.ptr.value + 96 * (ll + 2), 96 * (hl - ll))
+        pkg.vec_scale(curve, d_sc.ptr.value + 96 * ((hh - lh) + (hl - ll)), d_w.ptr.value + 96 * lb, r, hb - lb)
+        sets["C"].msm_start(d_sc.ptr.value, n_c_set)
+    else:
+        start("H")
+    partial = {name: sets[name].msm_finish() for name, _ in results}
     t_msm = time.perf_counter()
 
-    # one exchange per proof: the five partial points of this rank
-    flat = np.concatenate([partial[name] for name, _, _, _ in layout])
+    # one exchange per proof: the partial points of this rank
+    flat = np.concatenate([partial[name] for name, _ in results])
     if world > 1:
         gathered = pkg.parallel.all_gather_points(flat, device)
     else:
         gathered = [flat]
     total, pos = {}, 0
-    for name, group, _, _ in layout:
+    for name, group in results:
         pw = pkg.projective_words(curve, group)
         total[name] = pkg.parallel.fold_partials(pkg.api, curve, group, [g[pos:pos + pw] for g in gathered])
         pos += pw
     t_fold = time.perf_counter()
 
     if rank == 0:
-        scaled = pkg.point_scale(curve, 1, r, total["B1"])
-        c = pkg.point_add(curve, 1, total["H"], pkg.point_add(curve, 1, total["L"], scaled))
+        if fused:
+            c = total["C"]
+        else:
+            scaled = pkg.point_scale(curve, 1, r, total["B1"])
+            c = pkg.point_add(curve, 1, total["H"], pkg.point_add(curve, 1, total["L"], scaled))
         with open(output_path, "wb") as f:
             pkg.point_to_affine(curve, 1, total["A"]).tofile(f)
             pkg.point_to_affine(curve, 2, total["B2"]).tofile(f)
             pkg.point_to_affine(curve, 1, c).tofile(f)
         t_out = time.perf_counter()
         print(json.dumps({"curve": sys.argv[1], "n_gpus": world, "d": d, "m": m,
-                          "load_params_s": t_params - t0, "input_streamed_behind_4_msms_s": t_in - t_params,
+                          "fused_c": fused, "load_params_s": t_params - t0, "input_streamed_behind_the_w_msms_s": t_in - t_params,
                           "compute_h_and_remaining_msm_s": t_msm - t_in, "exchange_and_fold_s": t_fold - t_msm,
                           "total_input_to_output_s": t_out - t_params}), flush=True)
     if world > 1:

@@ -74,6 +74,7 @@ def lib():
         "mnt753_divide_by_z_on_coset": (i, [vp, vp, vp]),
         "mnt753_vec_muleq": (i, [i, vp, vp, sz, vp]),
         "mnt753_vec_subeq": (i, [i, vp, vp, sz, vp]),
+        "mnt753_vec_scale": (i, [i, vp, vp, vp, sz, vp]),
         "mnt753_compute_h": (i, [vp, vp, vp, vp, vp, vp]),
         "mnt753_synth_points": (i, [i, i, C.c_uint64, sz, u64p, i]),
         "mnt753_synth_scalars": (i, [i, C.c_uint64, sz, u64p]),
@@ -285,6 +286,19 @@ class Domain:
 def vec_muleq(curve, a_ptr, b_ptr, n, stream=None):
     st = C.c_void_p(int(stream)) if stream else C.c_void_p()
     _check(lib().mnt753_vec_muleq(curve, C.c_void_p(int(a_ptr)), C.c_void_p(int(b_ptr)), n, st), "mnt753_vec_muleq")
+
+
+def copy_d2d(dst_ptr, src_ptr, nbytes):
+    """Asynchronous device-to-device copy on the default stream (mnt753_copy_d2d)."""
+    _check(lib().mnt753_copy_d2d(C.c_void_p(int(dst_ptr)), C.c_void_p(int(src_ptr)), int(nbytes)), "mnt753_copy_d2d")
+
+
+def vec_scale(curve, dst_ptr, src_ptr, scalar, n, stream=None):
+    """dst[i] = src[i] * scalar (scalar: 12 uint64 on the host, wire format)."""
+    st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+    k = np.ascontiguousarray(scalar, dtype=np.uint64)
+    assert k.size == 12
+    _check(lib().mnt753_vec_scale(curve, C.c_void_p(int(dst_ptr)), C.c_void_p(int(src_ptr)), k.ctypes.data_as(C.c_void_p), n, st), "mnt753_vec_scale")
 
 
 def vec_subeq(curve, a_ptr, b_ptr, n, stream=None):

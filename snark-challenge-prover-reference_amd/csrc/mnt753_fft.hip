@@ -229,6 +229,21 @@ int mnt753_vec_muleq(int curve, uint64_t* dev_a, const uint64_t* dev_b, size_t n
   return 0;
 }
 
+int mnt753_vec_scale(int curve, uint64_t* dev_dst, const uint64_t* dev_src, const uint64_t* host_scalar, size_t n, void* stream) {
+  if (curve < 0 || curve > 1 || !host_scalar || (n && (!dev_dst || !dev_src))) return set_error(MNT753_EINVAL, "vec_scale: bad argument");
+  if (int rc = require_device()) return rc;
+  if (n == 0) return 0;
+  const unsigned gb = (unsigned)((n + 255) / 256);
+  WireElem k;
+  memcpy(k.w, host_scalar, 96);
+  uint32_t* d = reinterpret_cast<uint32_t*>(dev_dst);
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(dev_src);
+  if (curve == MNT753_CURVE_MNT4753) hipLaunchKernelGGL((k_vec_scale<MOD_A>), dim3(gb), dim3(256), 0, (hipStream_t)stream, d, s, k, n);
+  else hipLaunchKernelGGL((k_vec_scale<MOD_B>), dim3(gb), dim3(256), 0, (hipStream_t)stream, d, s, k, n);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int mnt753_vec_subeq(int curve, uint64_t* dev_a, const uint64_t* dev_b, size_t n, void* stream) {
   if (curve < 0 || curve > 1 || (n && (!dev_a || !dev_b))) return set_error(MNT753_EINVAL, "vec_subeq: bad argument");
   if (int rc = require_device()) return rc;

@@ -159,6 +159,25 @@ __global__ void __launch_bounds__(256) k_vec_muleq(uint32_t* __restrict__ a, con
   store_wire24(a + i * 24, w);
 }
 
+// dst[i] = src[i] * k          all wire form, k passed by value (one element, 24 words); dst may be src
+struct WireElem { uint32_t w[24]; };
+template <int M>
+__global__ void __launch_bounds__(256) k_vec_scale(uint32_t* __restrict__ dst, const uint32_t* src, WireElem kw, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[24];
+  Fp<M> x, y, t, r, k, c;
+  load_wire24(w, src + i * 24);
+  fp_unpack(x, w);
+  fp_unpack(y, kw.w);
+  fp_mul(t, x, y);
+  fp_const_limbs(k, FPC[M].k_in);
+  fp_mul(r, t, k);
+  fp_canon(c, r);
+  fp_pack(w, c);
+  store_wire24(dst + i * 24, w);
+}
+
 // a[i] = a[i] - b[i]
 template <int M>
 __global__ void __launch_bounds__(256) k_vec_subeq(uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n) {

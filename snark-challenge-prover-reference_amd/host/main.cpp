@@ -1,4 +1,4 @@
-// ./main_hip <curve> compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--point-cus N] [--unfused-h] [--ref-order] [--quiet]
+// ./main_hip <curve> compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--point-cus N] [--unfused-h] [--unfused-c] [--ref-order] [--quiet]
 //            --serve: keep the parameters resident and prove further "<input> <output>" pairs read from stdin, one per line
 // ./main_hip <curve> compute-r1cs <params> <r1cs> <witness> <output> ...      (ca / cb / cc evaluated on the device from the constraint system)
 // ./main_hip <curve> complete <keys> <input|witness> <challenge_proof> <full_proof> [--s-file <Fr> | --s-seed N]
@@ -23,12 +23,18 @@
 // Defaults = the fastest schedule on one MI355X: the G2 MSM is enqueued as soon as w is on the device, compute_H (one fused
 // call) follows as soon as ca / cb / cc are, then the four G1 MSMs.  The point kernels occupy every SIMD with long-lived
 // workgroups, so the ~60 short NTT kernels of compute_H must not be enqueued behind four MSMs (measured: 0.24 s with this
-// order, 0.44-1.1 s with the reference's source order).  --ref-order keeps the order of cuda_prover_piecewise.cu:64-81,
-// --unfused-h the reference's sequence of B:: calls inside compute_H (cuda_prover_piecewise.cu:24-47); every combination
-// writes the same bytes.
+// order, 0.44-1.1 s with the reference's source order), and C = Ht + Lt + r Bt1 is one MSM over the concatenated base set
+// (B::groth16_C).  --ref-order keeps the call sequence of cuda_prover_piecewise.cu:64-90 (five multiexps, compute_H after the
+// first three, G1_scale, two G1_add -- the wrapper still runs the last three multiexps and that tail as one MSM, see LazyPoint in
+// prover_hip_functions.cpp), --unfused-c loads the parameters as five base sets and runs the five multiexps, --unfused-h the
+// reference's sequence of B:: calls inside compute_H (cuda_prover_piecewise.cu:24-47); every combination writes the same bytes.
 static bool g_fused_h = true;
 static bool g_quiet = false;
 static bool g_h_first = true;
+static bool g_c_first = true;    // fused C: its MSM (3x the points of A's) is enqueued ahead of A's; --c-last the other way round
+static bool g_explicit_c = true;   // call B::groth16_C; off (--ref-order): the reference's calls, which the wrapper fuses by itself when the parameters are fused
+static bool g_touch_all = false;   // --touch-all (with --ref-order): read Bt1, Lt, Ht before they are combined -- with fused parameters that forces the three separate MSMs
+static bool g_fused_c = true;   // C = Ht + Lt + r Bt1 as one MSM over H | L | B1 (B::groth16_C); --unfused-c / --ref-order: the reference's five multiexps
 static int g_gpus = 0;   // --gpus N: parameter vectors sharded over N devices of this node (0: MNT753_GPUS or 1)
 static bool g_serve = false;    // --serve: after the listed jobs, read further "<input> <output>" lines from stdin until EOF
 static int g_point_cus = 256;   // --point-cus N: CUs the point kernels are sized for (include/mnt753_hip.h, mnt753_msm_set_point_cus)
@@ -78,59 +84,77 @@ void prove_one(typename B::groth16_params* params, const char* input_path, const
 
   auto w = B::input_w(input);
   auto ca = B::input_ca(input), cb = B::input_cb(input), cc = B::input_cc(input);
-  auto pA = B::params_A(params); auto pB1 = B::params_B1(params); auto pB2 = B::params_B2(params);
-  auto pH = B::params_H(params); auto pL = B::params_L(params);
+  auto pA = B::params_A(params); auto pB2 = B::params_B2(params);
   // Same operations as cuda_prover_piecewise.cu:64-81, in an order that follows the data: B::read_input streams the
   // file in the background (w first), B::multiexp_* only enqueue work, so the G2 MSM -- the longest, and it needs nothing
   // but w -- starts as soon as w is on the device, while ca / cb / cc are still loading.
   typename B::G2* evaluation_Bt2 = B::multiexp_G2(w, pB2, B::params_m(params) + 1);
-  typename B::G1 *evaluation_At, *evaluation_Bt1, *evaluation_Lt, *evaluation_Ht;
+  typename B::G1 *evaluation_At, *C;
   auto w_off = B::vector_Fr_offset(w, primary_input_size + 1);
   typename B::vector_Fr* coefficients_for_H;
-  auto t_h = clk::now();
-  if (g_h_first) {
-    // compute_H right behind the G2 MSM: its short kernels are not starved by four G1 accumulation phases, and the H MSM
-    // overlaps the others instead of running alone at the end
-    coefficients_for_H = compute_H<B>(B::params_d(params), ca, cb, cc);
-    t_h = clk::now();
-    evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
-    evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
-    evaluation_Bt1 = B::multiexp_G1(w, pB1, B::params_m(params) + 1);
-    evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
-  } else {
-    evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
-    evaluation_Bt1 = B::multiexp_G1(w, pB1, B::params_m(params) + 1);
-    evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
-    coefficients_for_H = compute_H<B>(B::params_d(params), ca, cb, cc);
-    t_h = clk::now();
-    evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
-  }
-  // the five MSMs run concurrently on their base sets' streams; touching the results waits for them
-  (void)B::G1_words(evaluation_At); (void)B::G1_words(evaluation_Bt1); (void)B::G2_words(evaluation_Bt2);
-  (void)B::G1_words(evaluation_Ht); (void)B::G1_words(evaluation_Lt);
-  auto t_msm = clk::now();
-
   auto r = B::input_r(input);
-  auto scaled_Bt1 = B::G1_scale(r, evaluation_Bt1);
-  auto Lt1_plus_scaled_Bt1 = B::G1_add(evaluation_Lt, scaled_Bt1);
-  auto C = B::G1_add(evaluation_Ht, Lt1_plus_scaled_Bt1);
-  auto t_c = clk::now();
+  auto t_h = clk::now();
+  clk::time_point t_msm, t_c;
+  if (g_fused_c && g_explicit_c) {
+    // Ht + Lt + r Bt1 is one group element: one MSM over the concatenated base set H | L | B1 with the scalars h | w_off | r w
+    // (B::groth16_C) instead of three MSMs, a scalar multiplication and two additions -- what an MSM pays per call and per bucket
+    // is paid once.  It needs coefficients_for_H, so compute_H goes first, right behind the G2 MSM.
+    coefficients_for_H = compute_H<B>(B::params_d(params), ca, cb, cc);
+    t_h = clk::now();
+    if (g_c_first) C = B::groth16_C(params, coefficients_for_H, w_off, w, r);
+    evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
+    if (!g_c_first) C = B::groth16_C(params, coefficients_for_H, w_off, w, r);
+    (void)B::G1_words(evaluation_At); (void)B::G2_words(evaluation_Bt2); (void)B::G1_words(C);
+    t_msm = t_c = clk::now();
+  } else {
+    auto pB1 = B::params_B1(params); auto pH = B::params_H(params); auto pL = B::params_L(params);
+    typename B::G1 *evaluation_Bt1, *evaluation_Lt, *evaluation_Ht;
+    if (g_h_first) {
+      // compute_H right behind the G2 MSM: its short kernels are not starved by four G1 accumulation phases, and the H MSM
+      // overlaps the others instead of running alone at the end
+      coefficients_for_H = compute_H<B>(B::params_d(params), ca, cb, cc);
+      t_h = clk::now();
+      evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
+      evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
+      evaluation_Bt1 = B::multiexp_G1(w, pB1, B::params_m(params) + 1);
+      evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
+    } else {
+      evaluation_At = B::multiexp_G1(w, pA, B::params_m(params) + 1);
+      evaluation_Bt1 = B::multiexp_G1(w, pB1, B::params_m(params) + 1);
+      evaluation_Lt = B::multiexp_G1(w_off, pL, B::params_m(params) - 1);
+      coefficients_for_H = compute_H<B>(B::params_d(params), ca, cb, cc);
+      t_h = clk::now();
+      evaluation_Ht = B::multiexp_G1(coefficients_for_H, pH, B::params_d(params));
+    }
+    // the five MSMs run concurrently on their base sets' streams; touching the results waits for them.  (With fused parameters
+    // Bt1, Lt and Ht are not computed at all: the wrapper recognises Ht + (Lt + r Bt1) below and runs it as one MSM -- touching
+    // them here would force the three separate ones.)
+    (void)B::G1_words(evaluation_At); (void)B::G2_words(evaluation_Bt2);
+    if (!g_fused_c || g_touch_all) { (void)B::G1_words(evaluation_Bt1); (void)B::G1_words(evaluation_Ht); (void)B::G1_words(evaluation_Lt); }
+    t_msm = clk::now();
+    auto scaled_Bt1 = B::G1_scale(r, evaluation_Bt1);
+    auto Lt1_plus_scaled_Bt1 = B::G1_add(evaluation_Lt, scaled_Bt1);
+    C = B::G1_add(evaluation_Ht, Lt1_plus_scaled_Bt1);
+    (void)B::G1_words(C);
+    t_c = clk::now();
+    B::delete_G1(evaluation_Bt1); B::delete_G1(evaluation_Ht); B::delete_G1(evaluation_Lt);
+    B::delete_G1(scaled_Bt1); B::delete_G1(Lt1_plus_scaled_Bt1);
+    B::delete_vector_G1(pB1); B::delete_vector_G1(pH); B::delete_vector_G1(pL);
+  }
   B::groth16_output_write(evaluation_At, evaluation_Bt2, C, output_path);
   auto t_out = clk::now();
   if (!g_quiet) {
-    printf("G2 MSM enqueued + compute_H (input streaming in): %.3fs\nremaining MSM time: %.3fs\nC = Ht + Lt + r*Bt1: %.3fs\ngpu: %.3fs\nstore: %.3fs\n", secs(t_in, t_h), secs(t_h, t_msm),
-           secs(t_msm, t_c), secs(t_in, t_c), secs(t_c, t_out));
+    printf("G2 MSM enqueued + compute_H (input streaming in): %.3fs\nremaining MSM time: %.3fs\nC = Ht + Lt + r*Bt1: %.3fs%s\ngpu: %.3fs\nstore: %.3fs\n", secs(t_in, t_h), secs(t_h, t_msm),
+           secs(t_msm, t_c), g_fused_c ? " (one MSM over H | L | B1)" : "", secs(t_in, t_c), secs(t_c, t_out));
     printf("input file on the device after: %.3fs (background loader)\n", B::input_load_seconds(input));
     printf("Total time from input to output: %.3fs\n", secs(t_main, t_out));
     if (first) printf("Total wall (incl. load params): %.3fs\n", secs(t0, t_out));
   }
 
-  B::delete_G1(evaluation_At); B::delete_G1(evaluation_Bt1); B::delete_G2(evaluation_Bt2);
-  B::delete_G1(evaluation_Ht); B::delete_G1(evaluation_Lt);
-  B::delete_G1(scaled_Bt1); B::delete_G1(Lt1_plus_scaled_Bt1); B::delete_G1(C);
+  B::delete_G1(evaluation_At); B::delete_G2(evaluation_Bt2); B::delete_G1(C);
   B::delete_vector_Fr(coefficients_for_H); B::delete_vector_Fr(w); B::delete_vector_Fr(w_off);
   B::delete_vector_Fr(ca); B::delete_vector_Fr(cb); B::delete_vector_Fr(cc);
-  B::delete_vector_G1(pA); B::delete_vector_G1(pB1); B::delete_vector_G2(pB2); B::delete_vector_G1(pH); B::delete_vector_G1(pL);
+  B::delete_vector_G1(pA); B::delete_vector_G2(pB2);
   B::delete_field(r);   // (the reference's wrapper has no delete_field and its driver leaks the element)
   B::delete_groth16_input(input);
 }
@@ -140,6 +164,7 @@ template <typename B>
 void run_prover(const char* params_path, const std::vector<std::pair<std::string, std::string>>& jobs, const char* r1cs_path = nullptr) {
   if (g_gpus > 0) B::use_devices(g_gpus);
   (void)mnt753_msm_set_point_cus(g_point_cus);
+  B::fuse_C(g_fused_c);
   B::init_public_params();
   auto t0 = clk::now();
   auto params = B::read_params(params_path);
@@ -264,7 +289,12 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--quiet")) g_quiet = true;
     else if (!strcmp(argv[i], "--serve")) g_serve = true;
     else if (!strcmp(argv[i], "--h-first")) g_h_first = true;
-    else if (!strcmp(argv[i], "--h-last") || !strcmp(argv[i], "--ref-order")) g_h_first = false;
+    else if (!strcmp(argv[i], "--h-last")) g_h_first = false;
+    else if (!strcmp(argv[i], "--ref-order")) { g_h_first = false; g_explicit_c = false; }   // the call sequence of cuda_prover_piecewise.cu:64-90
+    else if (!strcmp(argv[i], "--unfused-c")) g_fused_c = false;
+    else if (!strcmp(argv[i], "--c-last")) g_c_first = false;
+    else if (!strcmp(argv[i], "--touch-all")) g_touch_all = true;
+    else if (!strcmp(argv[i], "--fused-c")) g_fused_c = true;
   }
   std::string curve(argv[1]), mode(argv[2]);
   try {

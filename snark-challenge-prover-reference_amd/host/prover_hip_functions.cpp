@@ -91,6 +91,13 @@ struct BaseSetHolder {
   ~BaseSetHolder() { if (h) mnt753_bases_free(h); }
 };
 static int g_n_devices = 0;   // 0: not chosen yet (init_public_params reads MNT753_GPUS, default 1)
+// Ht + Lt + r Bt1 as ONE multi-scalar multiplication over the concatenated base set H | L | B1 (B::groth16_C).  -1: not chosen yet
+// (read_params reads MNT753_FUSED_C, default on).
+static int g_fused_c = -1;
+static bool fused_c() {
+  if (g_fused_c < 0) { const char* e = getenv("MNT753_FUSED_C"); g_fused_c = e ? (atoi(e) != 0) : 1; }
+  return g_fused_c != 0;
+}
 // contiguous slice g of n elements over n_dev devices (multiexp.tcc:417-431: one = n / chunks, the last slice takes the remainder)
 static void slice_bounds(size_t n, int n_dev, int g, size_t* lo, size_t* hi) {
   const size_t one = n / (size_t)n_dev;
@@ -116,7 +123,29 @@ struct ShardedBases {
   size_t n = 0;
 };
 // one MSM in flight on every slice of a sharded vector
-struct PendingMsm { std::vector<std::shared_ptr<BaseSetHolder>> sets; };
+struct PendingMsm {
+  std::vector<std::shared_ptr<BaseSetHolder>> sets;
+  std::shared_ptr<DeviceBuffer> scalars;   // scalar vector assembled for this MSM alone (groth16_C): lives as long as the MSM does
+};
+// A G1 value that has not been computed yet.  With the concatenated base set H | L | B1 resident (fused parameters), the three
+// multiexps over B1, L and H are not started when the driver asks for them: cuda_prover_piecewise.cu:79-90 only ever uses their
+// results in  C = Ht + (Lt + r * Bt1),  and that whole expression is ONE multi-scalar multiplication over the concatenated set.
+// B::multiexp_G1 / G1_scale / G1_add therefore build this little expression tree, and the addition that completes the pattern starts
+// the single MSM.  Anything else a caller does with such a value (print it, write it, add it to something unrelated) evaluates the
+// tree the plain way -- each MSM on its own base set, built on first use.
+struct LazyPoint {
+  enum Kind { VALUE, MSM, SCALE, ADD } kind = VALUE;
+  uint64_t value[36] = {0};                       // VALUE: projective, wire format
+  void* owner = nullptr;                          // MSM: the groth16_params the base vector belongs to,
+  int which = 0;                                  //      which of its vectors (1 B1, 2 L, 3 H),
+  size_t length = 0;                              //      and the scalars (kept alive by `keep`)
+  std::function<const uint64_t*()> scalars;
+  std::shared_ptr<std::vector<DevSlice>> slices;
+  size_t offset = 0;
+  std::shared_ptr<void> keep;
+  uint64_t k[12] = {0};                           // SCALE: k * a
+  std::shared_ptr<LazyPoint> a, b;                // SCALE: a;  ADD: a + b
+};
 struct DomainHolder {
   mnt753_domain* h = nullptr;
   ~DomainHolder() { if (h) mnt753_domain_free(h); }
@@ -132,7 +161,7 @@ using namespace mnt753_hip_detail;
 template <int CURVE> struct mnt753_hip_impl<CURVE>::evaluation_domain { std::shared_ptr<DomainHolder> data; };
 template <int CURVE> struct mnt753_hip_impl<CURVE>::field { uint64_t data[12]; };
 // G1 / G2 returned by multiexp_* are lazy: the MSM is in flight on its base set's stream until the value is first used
-template <int CURVE> struct mnt753_hip_impl<CURVE>::G1 { uint64_t data[36]; std::shared_ptr<PendingMsm> pending; };
+template <int CURVE> struct mnt753_hip_impl<CURVE>::G1 { uint64_t data[36]; std::shared_ptr<PendingMsm> pending; std::shared_ptr<LazyPoint> lazy; };
 template <int CURVE> struct mnt753_hip_impl<CURVE>::G2 { uint64_t data[108]; std::shared_ptr<PendingMsm> pending; };  // 72 used on MNT4753, 108 on MNT6753
 template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
   std::shared_ptr<DeviceBuffer> data;
@@ -148,7 +177,8 @@ template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
     return reinterpret_cast<uint64_t*>(data->ptr) + 12 * offset;
   }
 };
-template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G1 { std::shared_ptr<ShardedBases> data; };
+// owner / which: set for B1 (1), L (2), H (3) of fused parameters, whose own base sets exist only once something needs them
+template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G1 { std::shared_ptr<ShardedBases> data; groth16_params* owner = nullptr; int which = 0; };
 template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G2 { std::shared_ptr<ShardedBases> data; };
 
 // params file: u64 d, u64 m, A[m+1] G1, B1[m+1] G1, B2[m+1] G2, L[m-1] G1, H[d] G1
@@ -157,19 +187,40 @@ template <int CURVE>
 class mnt753_hip_impl<CURVE>::groth16_params {
 public:
   size_t d = 0, m = 0;
-  std::shared_ptr<ShardedBases> A, B1, L, H, B2;
-  explicit groth16_params(const char* path) {
-    FILE* f = fopen(path, "rb");
+  // A and B2 always; B1, L, H either as three base sets (the reference's five multiexps) or, fused, as the one concatenated set HLB
+  // = H[d] | L[m-1] | B1[m+1] that B::groth16_C multiplies in one pass -- the three separate sets are then built on first use only
+  // (B::params_B1 / params_L / params_H), from the file.
+  std::shared_ptr<ShardedBases> A, B1, L, H, B2, HLB;
+  std::string path;
+  size_t off_B1 = 0, off_L = 0, off_H = 0;   // byte offsets of the vectors in the params file
+  std::mutex mu;
+  static std::shared_ptr<ShardedBases> make_set(int group, size_t words, size_t n, const uint64_t* host) {
+    const int n_dev = std::max(1, mnt753_device_count());
+    auto sb = std::make_shared<ShardedBases>();
+    sb->n = n;
+    struct BackToDevice0 { int n; ~BackToDevice0() { if (n > 1) (void)mnt753_set_device(0); } } back{n_dev};   // also when a creation throws
+    for (int g = 0; g < n_dev; ++g) {
+      ShardedBases::Part part;
+      slice_bounds(n, n_dev, g, &part.lo, &part.hi);
+      part.set = std::make_shared<BaseSetHolder>();
+      if (n_dev > 1) check(mnt753_set_device(g), "mnt753_set_device");
+      check(mnt753_bases_create(CURVE, group, host + words * part.lo, 0, part.hi - part.lo, &part.set->h), "mnt753_bases_create");
+      sb->parts.push_back(part);
+    }
+    return sb;
+  }
+  explicit groth16_params(const char* path_) : path(path_) {
+    FILE* f = fopen(path_, "rb");
     if (!f) throw std::runtime_error(std::string("cannot open params file ") + path);
     uint64_t dm[2];
-    read_exact(f, dm, 16, path);
+    read_exact(f, dm, 16, path_);
     d = dm[0]; m = dm[1];
     const size_t g1w = mnt753_affine_words(CURVE, MNT753_G1), g2w = mnt753_affine_words(CURVE, MNT753_G2);
     // The reference trusts d and m (prover_reference_functions.cpp:86-116); here they size device allocations, so they
     // are checked against the file before anything is allocated: 16 + 8*(g1w*(3m + d + 1) + g2w*(m + 1)) bytes exactly.
     {
       struct stat st;
-      if (m < 2 || d < 1 || m > ((size_t)1 << 31) || d > ((size_t)1 << 31) || stat(path, &st) != 0) {
+      if (m < 2 || d < 1 || m > ((size_t)1 << 31) || d > ((size_t)1 << 31) || stat(path_, &st) != 0) {
         fclose(f);
         throw std::runtime_error(std::string("bad params header (d, m) in ") + path);
       }
@@ -180,28 +231,50 @@ public:
                                  ", expected " + std::to_string(expect) + " bytes, found " + std::to_string((unsigned long long)st.st_size) + "): " + path);
       }
     }
-    const int n_dev = std::max(1, mnt753_device_count());
-    auto load = [&](int group, size_t words, size_t n) {
-      std::vector<uint64_t> host(words * n);
-      read_exact(f, host.data(), host.size() * 8, path);
-      auto sb = std::make_shared<ShardedBases>();
-      sb->n = n;
-      for (int g = 0; g < n_dev; ++g) {
-        ShardedBases::Part part;
-        slice_bounds(n, n_dev, g, &part.lo, &part.hi);
-        part.set = std::make_shared<BaseSetHolder>();
-        if (n_dev > 1) check(mnt753_set_device(g), "mnt753_set_device");
-        check(mnt753_bases_create(CURVE, group, host.data() + words * part.lo, 0, part.hi - part.lo, &part.set->h), "mnt753_bases_create");
-        sb->parts.push_back(part);
+    off_B1 = 16 + 8 * g1w * (m + 1);
+    off_L = off_B1 + 8 * (g1w + g2w) * (m + 1);
+    off_H = off_L + 8 * g1w * (m - 1);
+    const bool fused = fused_c();
+    std::vector<uint64_t> host, cat;
+    auto load = [&](int group, size_t words, size_t n, size_t cat_at) {
+      host.resize(words * n);
+      read_exact(f, host.data(), host.size() * 8, path_);
+      if (fused && group == MNT753_G1 && cat_at != (size_t)-1) {   // a part of the concatenated set: keep the host copy, no set of its own
+        memcpy(cat.data() + g1w * cat_at, host.data(), host.size() * 8);
+        return std::shared_ptr<ShardedBases>();
       }
-      if (n_dev > 1) check(mnt753_set_device(0), "mnt753_set_device");
-      return sb;
+      return make_set(group, words, n, host.data());
     };
-    A = load(MNT753_G1, g1w, m + 1);
-    B1 = load(MNT753_G1, g1w, m + 1);
-    B2 = load(MNT753_G2, g2w, m + 1);
-    L = load(MNT753_G1, g1w, m - 1);
-    H = load(MNT753_G1, g1w, d);
+    if (fused) cat.resize(g1w * (d + 2 * m));
+    try {
+      A = load(MNT753_G1, g1w, m + 1, (size_t)-1);
+      B1 = load(MNT753_G1, g1w, m + 1, d + m - 1);
+      B2 = load(MNT753_G2, g2w, m + 1, (size_t)-1);
+      L = load(MNT753_G1, g1w, m - 1, d);
+      H = load(MNT753_G1, g1w, d, 0);
+      if (fused) HLB = make_set(MNT753_G1, g1w, d + 2 * m, cat.data());
+    } catch (...) { fclose(f); throw; }
+    fclose(f);
+  }
+  // B1, L, H as base sets of their own (the reference's call sequence asks for them): built now if the parameters were loaded fused
+  void ensure_separate() {
+    std::lock_guard<std::mutex> l(mu);
+    if (B1 && L && H) return;
+    const size_t g1w = mnt753_affine_words(CURVE, MNT753_G1);
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open params file ") + path);
+    std::vector<uint64_t> host;
+    auto load_at = [&](size_t off, size_t n) {
+      host.resize(g1w * n);
+      if (fseeko(f, (off_t)off, SEEK_SET) != 0) { fclose(f); throw std::runtime_error(std::string("seek failed: ") + path); }
+      read_exact(f, host.data(), host.size() * 8, path.c_str());
+      return make_set(MNT753_G1, g1w, n, host.data());
+    };
+    try {
+      if (!B1) B1 = load_at(off_B1, m + 1);
+      if (!L) L = load_at(off_L, m - 1);
+      if (!H) H = load_at(off_H, d);
+    } catch (...) { fclose(f); throw; }
     fclose(f);
   }
 };
@@ -391,7 +464,11 @@ template <int CURVE, int GROUP, class P> static void resolve_t(P* p) {
   }
   p->pending.reset();
 }
-template <int CURVE> static void resolve(typename mnt753_hip_impl<CURVE>::G1* p) { resolve_t<CURVE, MNT753_G1>(p); }
+template <int CURVE> static void evaluate_lazy(typename mnt753_hip_impl<CURVE>::G1* p);   // below, behind start_sharded
+template <int CURVE> static void resolve(typename mnt753_hip_impl<CURVE>::G1* p) {
+  if (p->lazy) evaluate_lazy<CURVE>(p);
+  resolve_t<CURVE, MNT753_G1>(p);
+}
 template <int CURVE> static void resolve(typename mnt753_hip_impl<CURVE>::G2* p) { resolve_t<CURVE, MNT753_G2>(p); }
 
 template <int CURVE> void HIP_B::use_devices(int n) { g_n_devices = n < 1 ? 1 : n; }
@@ -442,14 +519,39 @@ template <int CURVE> typename HIP_B::evaluation_domain* HIP_B::get_evaluation_do
   return new evaluation_domain{cached_domain<CURVE>(d)};
 }
 
+template <int CURVE> static std::shared_ptr<PendingMsm> try_fuse(const std::shared_ptr<LazyPoint>& root);   // below
+// the expression node of a G1 operand: its tree if it has one, else its value
+template <int CURVE> static std::shared_ptr<LazyPoint> node_of(typename mnt753_hip_impl<CURVE>::G1* a) {
+  if (a->lazy) return a->lazy;
+  resolve<CURVE>(a);
+  auto n = std::make_shared<LazyPoint>();
+  memcpy(n->value, a->data, sizeof(n->value));
+  return n;
+}
 template <int CURVE> typename HIP_B::G1* HIP_B::G1_add(G1* a, G1* b) {
   G1* r = new G1();
+  if (a->lazy || b->lazy) {
+    auto n = std::make_shared<LazyPoint>();
+    n->kind = LazyPoint::ADD;
+    n->a = node_of<CURVE>(a); n->b = node_of<CURVE>(b);
+    // Ht + (Lt + r Bt1) complete: the one MSM over H | L | B1 starts here
+    if (auto pend = try_fuse<CURVE>(n)) r->pending = pend; else r->lazy = n;
+    return r;
+  }
   resolve<CURVE>(a); resolve<CURVE>(b);
   check(mnt753_point_add(CURVE, MNT753_G1, a->data, b->data, r->data), "mnt753_point_add");
   return r;
 }
 template <int CURVE> typename HIP_B::G1* HIP_B::G1_scale(field* a, G1* b) {
   G1* r = new G1();
+  if (b->lazy) {
+    auto n = std::make_shared<LazyPoint>();
+    n->kind = LazyPoint::SCALE;
+    memcpy(n->k, a->data, sizeof(n->k));
+    n->a = b->lazy;
+    r->lazy = n;
+    return r;
+  }
   resolve<CURVE>(b);
   check(mnt753_point_scale(CURVE, MNT753_G1, a->data, b->data, r->data), "mnt753_point_scale");
   return r;
@@ -542,8 +644,104 @@ static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarS
 template <class V> static ScalarSource source_of(V* v) {
   return ScalarSource{[v]() { return v->ptr(); }, v->slices.get(), v->offset};
 }
+// the scalars h | w_L | r w of the concatenated sum, assembled on device 0's default stream (two copies and one scaling pass, ~0.2 ms:
+// behind compute_H, ahead of the MSM), and the MSM over H | L | B1
+template <int CURVE>
+static std::shared_ptr<PendingMsm> start_fused_c(typename HIP_B::groth16_params* p, const uint64_t* h, const uint64_t* w_L, const uint64_t* w, const uint64_t* r) {
+  const size_t d = p->d, m = p->m, n = d + 2 * m;
+  auto sc = std::make_shared<DeviceBuffer>(96 * n);
+  uint64_t* s = reinterpret_cast<uint64_t*>(sc->ptr);
+  check(mnt753_copy_d2d(s, h, 96 * d), "mnt753_copy_d2d");
+  check(mnt753_copy_d2d(s + 12 * d, w_L, 96 * (m - 1)), "mnt753_copy_d2d");
+  check(mnt753_vec_scale(CURVE, s + 12 * (d + m - 1), w, r, m + 1, nullptr), "mnt753_vec_scale");
+  auto pend = start_sharded(*p->HLB, ScalarSource{[s]() { return (const uint64_t*)s; }, nullptr, 0}, n, "mnt753_msm_start(C)");
+  pend->scalars = sc;
+  if (const char* e = getenv("MNT753_TRACE")) { if (atoi(e)) fprintf(stderr, "mnt753: C = Ht + Lt + r Bt1 as one MSM over H | L | B1 (%zu points)\n", n); }
+  return pend;
+}
+// Does the tree say Ht + Lt + r Bt1 -- in any association and order: exactly one unstarted MSM over each of H and L (unscaled) and B1
+// (scaled once), all of the same fused parameters and over the whole vectors?  Then start the one MSM; else null.
+template <int CURVE> static std::shared_ptr<PendingMsm> try_fuse(const std::shared_ptr<LazyPoint>& root) {
+  struct Term { const LazyPoint* msm; const uint64_t* k; };
+  std::vector<Term> terms;
+  std::function<bool(const LazyPoint*, const uint64_t*)> walk = [&](const LazyPoint* n, const uint64_t* k) -> bool {
+    switch (n->kind) {
+      case LazyPoint::ADD: return walk(n->a.get(), k) && walk(n->b.get(), k);
+      case LazyPoint::SCALE: return k == nullptr && walk(n->a.get(), n->k);
+      case LazyPoint::MSM: terms.push_back({n, k}); return terms.size() <= 3;
+      default: return false;
+    }
+  };
+  if (!walk(root.get(), nullptr) || terms.size() != 3) return nullptr;
+  const LazyPoint* t[4] = {nullptr, nullptr, nullptr, nullptr};
+  const uint64_t* r = nullptr;
+  for (const Term& term : terms) {
+    const int which = term.msm->which;
+    if (which < 1 || which > 3 || t[which] || term.msm->owner != terms[0].msm->owner) return nullptr;
+    if ((which == 1) != (term.k != nullptr)) return nullptr;
+    if (term.k) r = term.k;
+    t[which] = term.msm;
+  }
+  auto* p = static_cast<typename HIP_B::groth16_params*>(terms[0].msm->owner);
+  if (!p->HLB || t[1]->length != p->m + 1 || t[2]->length != p->m - 1 || t[3]->length != p->d) return nullptr;
+  return start_fused_c<CURVE>(p, t[3]->scalars(), t[2]->scalars(), t[1]->scalars(), r);
+}
+// the plain way: every MSM on its own base set (built now if the parameters were loaded fused), one after the other
+template <int CURVE> static void lazy_value(LazyPoint& n, uint64_t* out) {
+  switch (n.kind) {
+    case LazyPoint::VALUE: memcpy(out, n.value, sizeof(n.value)); return;
+    case LazyPoint::MSM: {
+      auto* p = static_cast<typename HIP_B::groth16_params*>(n.owner);
+      p->ensure_separate();
+      ShardedBases& sb = n.which == 1 ? *p->B1 : (n.which == 2 ? *p->L : *p->H);
+      typename HIP_B::G1 tmp;
+      tmp.pending = start_sharded(sb, ScalarSource{n.scalars, n.slices.get(), n.offset}, n.length, "mnt753_msm_start(G1)");
+      resolve_t<CURVE, MNT753_G1>(&tmp);
+      memcpy(out, tmp.data, sizeof(tmp.data));
+      return;
+    }
+    case LazyPoint::SCALE: {
+      uint64_t a[36];
+      lazy_value<CURVE>(*n.a, a);
+      check(mnt753_point_scale(CURVE, MNT753_G1, n.k, a, out), "mnt753_point_scale");
+      return;
+    }
+    case LazyPoint::ADD: {
+      uint64_t a[36], b[36];
+      lazy_value<CURVE>(*n.a, a); lazy_value<CURVE>(*n.b, b);
+      check(mnt753_point_add(CURVE, MNT753_G1, a, b, out), "mnt753_point_add");
+      return;
+    }
+  }
+}
+template <int CURVE> static void evaluate_lazy(typename mnt753_hip_impl<CURVE>::G1* p) {
+  auto node = p->lazy;
+  p->lazy.reset();
+  if (auto pend = try_fuse<CURVE>(node)) { p->pending = pend; return; }
+  lazy_value<CURVE>(*node, p->data);
+}
 template <int CURVE> typename HIP_B::G1* HIP_B::multiexp_G1(vector_Fr* scalar_start, vector_G1* g_start, size_t length) {
   G1* r = new G1();
+  if (g_start->which && !g_start->data) {
+    // B1, L or H of fused parameters: nothing runs yet (see LazyPoint) -- unless it is a partial vector, which only the set itself can do
+    groth16_params* p = g_start->owner;
+    const size_t full = g_start->which == 1 ? p->m + 1 : (g_start->which == 2 ? p->m - 1 : p->d);
+    if (p->HLB && length == full && scalar_start->size - scalar_start->offset >= length) {
+      auto n = std::make_shared<LazyPoint>();
+      n->kind = LazyPoint::MSM;
+      n->owner = p; n->which = g_start->which; n->length = length;
+      auto v = std::make_shared<vector_Fr>(*scalar_start);   // shares the buffer and its readiness latch
+      n->keep = v;
+      vector_Fr* vp = v.get();
+      n->scalars = [vp]() { return (const uint64_t*)vp->ptr(); };
+      n->slices = scalar_start->slices;
+      n->offset = scalar_start->offset;
+      r->lazy = n;
+      return r;
+    }
+    p->ensure_separate();
+    g_start->data = g_start->which == 1 ? p->B1 : (g_start->which == 2 ? p->L : p->H);
+  }
   r->pending = start_sharded(*g_start->data, source_of(scalar_start), length, "mnt753_msm_start(G1)");
   return r;
 }
@@ -552,6 +750,23 @@ template <int CURVE> typename HIP_B::G2* HIP_B::multiexp_G2(vector_Fr* scalar_st
   r->pending = start_sharded(*g_start->data, source_of(scalar_start), length, "mnt753_msm_start(G2)");
   return r;
 }
+
+// C = Ht + Lt + r Bt1 (cuda_prover_piecewise.cu:79-90) = sum_i h[i] H[i] + sum_i w_L[i] L[i] + sum_i (r w[i]) B1[i]: one multi-scalar
+// multiplication of d + 2m points over the concatenated set instead of three of ~m points each plus a scalar multiplication and two
+// additions.  Same group element, so the same bytes in the proof file; what it saves is everything an MSM pays per call and per
+// bucket rather than per point (sort, edge merge, bucket reduction: 3.2 of 25.8 ms at 2^20 points) -- one 3 * 2^20-point MSM
+// instead of three 2^20-point ones.  The scalar vector is assembled on device 0's default stream (two copies and one scaling pass,
+// ~0.2 ms), behind compute_H and ahead of the MSM.
+template <int CURVE> typename HIP_B::G1* HIP_B::groth16_C(groth16_params* p, vector_Fr* coefficients_for_H, vector_Fr* w_L, vector_Fr* w, field* r) {
+  if (!p->HLB) throw std::runtime_error("groth16_C: the parameters were loaded without the concatenated base set (B::fuse_C(false) / MNT753_FUSED_C=0)");
+  const size_t d = p->d, m = p->m;
+  if (coefficients_for_H->size - coefficients_for_H->offset < d || w_L->size - w_L->offset < m - 1 || w->size - w->offset < m + 1)
+    throw std::runtime_error("groth16_C: a scalar vector is shorter than its base vector");
+  G1* out = new G1();
+  out->pending = start_fused_c<CURVE>(p, coefficients_for_H->ptr(), w_L->ptr(), w->ptr(), r->data);
+  return out;
+}
+template <int CURVE> void HIP_B::fuse_C(bool on) { g_fused_c = on ? 1 : 0; }
 
 template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_input(const char* path, groth16_params* params) {
   return new groth16_input(path, params->d, params->m);
@@ -578,13 +793,16 @@ template <int CURVE> typename HIP_B::field* HIP_B::input_r(groth16_input* in) {
 // prover), the later ones always at 0.22 s.  MNT753_NO_WARMUP=1 turns it off.
 template <int CURVE> static void warm_up(typename mnt753_hip_impl<CURVE>::groth16_params* p) {
   if (const char* e = getenv("MNT753_NO_WARMUP")) { if (atoi(e) != 0) return; }
-  const size_t n = std::max(p->m + 1, p->d);
+  std::vector<ShardedBases*> sets;
+  for (auto* sb : {p->B2.get(), p->HLB.get(), p->A.get(), p->B1.get(), p->L.get(), p->H.get()}) if (sb) sets.push_back(sb);
+  size_t n = 1;
+  for (auto* sb : sets) n = std::max(n, sb->n);
   std::vector<uint64_t> host(12 * n);
   check(mnt753_synth_scalars(CURVE, 0x7761726dull, n, host.data()), "mnt753_synth_scalars");
   DeviceBuffer dev(96 * n);
   check(mnt753_copy_h2d(dev.ptr, host.data(), 96 * n), "mnt753_copy_h2d");
   std::vector<std::shared_ptr<PendingMsm>> pend;
-  for (auto* sb : {p->B2.get(), p->A.get(), p->B1.get(), p->L.get(), p->H.get()})
+  for (auto* sb : sets)
     pend.push_back(start_sharded(*sb, ScalarSource{[&dev]() { return reinterpret_cast<const uint64_t*>(dev.ptr); }, nullptr, 0}, sb->n, "mnt753_msm_start(warm-up)"));
   uint64_t sink[108];
   for (auto& pm : pend)
@@ -601,18 +819,20 @@ template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const ch
     pre.emplace_back(new DeviceBuffer(96 * (p->m + 1)));
     for (int k = 0; k < 3; ++k) pre.emplace_back(new DeviceBuffer(96 * (p->d + 1)));
     pre.emplace_back(new DeviceBuffer(96 * (m_dom + 1)));
+    if (p->HLB) pre.emplace_back(new DeviceBuffer(96 * (p->d + 2 * p->m)));   // the scalars of groth16_C
   }
   return p;
 }
 template <int CURVE> size_t HIP_B::params_d(groth16_params* p) { return p->d; }
 template <int CURVE> size_t HIP_B::params_m(groth16_params* p) { return p->m; }
 template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_A(groth16_params* p) { return new vector_G1{p->A}; }
-template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_B1(groth16_params* p) { return new vector_G1{p->B1}; }
-template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_L(groth16_params* p) { return new vector_G1{p->L}; }
-template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_H(groth16_params* p) { return new vector_G1{p->H}; }
+// B1, L, H of fused parameters: a handle only; the base set is built when a multiexp really needs it (multiexp_G1)
+template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_B1(groth16_params* p) { return new vector_G1{p->B1, p, 1}; }
+template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_L(groth16_params* p) { return new vector_G1{p->L, p, 2}; }
+template <int CURVE> typename HIP_B::vector_G1* HIP_B::params_H(groth16_params* p) { return new vector_G1{p->H, p, 3}; }
 template <int CURVE> typename HIP_B::vector_G2* HIP_B::params_B2(groth16_params* p) { return new vector_G2{p->B2}; }
 
-template <int CURVE> void HIP_B::delete_G1(G1* a) { if (a) resolve<CURVE>(a); delete a; }
+template <int CURVE> void HIP_B::delete_G1(G1* a) { if (a && !a->lazy) resolve<CURVE>(a); delete a; }   // an MSM in flight is waited for; one never started is dropped
 template <int CURVE> void HIP_B::delete_G2(G2* a) { if (a) resolve<CURVE>(a); delete a; }
 template <int CURVE> void HIP_B::delete_field(field* a) { delete a; }
 template <int CURVE> void HIP_B::delete_vector_Fr(vector_Fr* a) { delete a; }

@@ -81,6 +81,15 @@ def test_vector_ops_vs_oracle(gpu):
         diff = np.array([O.field_op(curve, 2, prod[i], b[i]) for i in range(n)])
         assert np.array_equal(da.to_numpy().reshape(n, 12), diff)
         gpu.vec_muleq(curve, da.ptr.value, db.ptr.value, 0)   # empty is a no-op
+        # dst = src * k with k on the host (the factor r of r * Bt1 folded into the scalars of B::groth16_C); in place as well
+        k = gpu.synth_scalars(curve, 3, 1)[0]
+        dd = gpu.DeviceBuffer.from_numpy(np.zeros_like(a))
+        gpu.vec_scale(curve, dd.ptr.value, db.ptr.value, k, n)
+        scaled = np.array([O.field_op(curve, 0, b[i], k) for i in range(n)])
+        assert np.array_equal(dd.to_numpy().reshape(n, 12), scaled)
+        gpu.vec_scale(curve, db.ptr.value, db.ptr.value, k, n)
+        assert np.array_equal(db.to_numpy().reshape(n, 12), scaled)
+        gpu.vec_scale(curve, db.ptr.value, db.ptr.value, k, 0)
 
 
 def test_full_size_2pow20_properties(gpu):

@@ -18,7 +18,8 @@ NAME = {0: "MNT4753", 1: "MNT6753"}
 
 
 @pytest.mark.parametrize("curve", [0, 1])
-@pytest.mark.parametrize("flags", [[], ["--unfused-h"], ["--ref-order"], ["--unfused-h", "--ref-order"]])
+@pytest.mark.parametrize("flags", [[], ["--unfused-h"], ["--ref-order"], ["--unfused-h", "--ref-order"], ["--unfused-c"], ["--c-last"],
+                                   ["--unfused-c", "--h-last"], ["--repeat", "2"], ["--ref-order", "--touch-all", "--repeat", "2"]])
 def test_reference_proof_files(gpu, curve, flags, tmp_path):
     params, inp, expected = G.e2e_paths(curve)
     out = str(tmp_path / "proof.bin")
@@ -87,9 +88,15 @@ def test_reference_driver_unchanged(gpu, curve, tmp_path):
         pytest.skip("oracle/_ref/piecewise_hip not built (tools/dropin_check.sh needs the reference tree)")
     params, inp, expected = G.e2e_paths(curve)
     out = str(tmp_path / "proof.bin")
-    r = subprocess.run([exe, NAME[curve], "compute", params, inp, out], capture_output=True, text=True)
+    r = subprocess.run([exe, NAME[curve], "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_TRACE="1"))
     assert r.returncode == 0, r.stderr
     assert filecmp.cmp(out, expected, shallow=False)
+    # ... and its three multiexps over B1 / L / H plus G1_scale and two G1_add ran as ONE MSM over the concatenated set (LazyPoint in
+    # host/prover_hip_functions.cpp), without a line of the driver knowing
+    assert "one MSM over H | L | B1" in r.stderr
+    r = subprocess.run([exe, NAME[curve], "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_TRACE="1", MNT753_FUSED_C="0"))
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(out, expected, shallow=False) and "one MSM" not in r.stderr
 
 
 @pytest.mark.parametrize("curve", [0, 1])

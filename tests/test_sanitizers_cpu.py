@@ -36,7 +36,7 @@ def test_host_paths_clean_under_sanitizers(san, kind, curve, tmp_path):
     params, inp, _ = G.e2e_paths(curve)
     out = str(tmp_path / "o")
     for flags in ([], ["--repeat", "3"], ["--gpus", "2", "--ref-order"], ["--gpus", "3", "--unfused-h", "--repeat", "2"], ["--gpus", "8"],
-                  [inp, str(tmp_path / "o2"), "--gpus", "4"]):
+                  [inp, str(tmp_path / "o2"), "--gpus", "4"], ["--unfused-c", "--repeat", "2"], ["--gpus", "3", "--unfused-c"], ["--c-last", "--gpus", "2"], ["--ref-order", "--touch-all", "--repeat", "2"], ["--ref-order", "--touch-all", "--gpus", "2"]):
         r = run(san[kind], [NAME[curve], "compute", params, inp, out] + flags)
         assert "Total time from input to output" in r.stdout
 

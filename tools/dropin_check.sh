@@ -20,4 +20,5 @@ NDIFF=$(sed -n '14,120p' $R/cuda_prover_piecewise.cu | diff - $GEN | grep -c '^>
 [ "$NDIFF" = "4" ] || { echo "dropin_check: expected 2 include lines + 2 swapped instantiations, found $NDIFF differing lines"; exit 1; }
 PKG=$HERE/snark-challenge-prover-reference_amd
 g++ -O2 -std=c++17 -pthread -I$HERE/include $GEN $PKG/host/prover_hip_functions.cpp -L$PKG -lmnt753_hip -Wl,-rpath,'$ORIGIN/../../snark-challenge-prover-reference_amd' -o $O/piecewise_hip
+rm -f $GEN   # the generated translation unit holds the reference's text: it is not kept, not even in the git-ignored directory
 echo "dropin_check: the reference driver compiled unchanged against prover_hip_functions.hpp -> oracle/_ref/piecewise_hip"

@@ -30,8 +30,11 @@ def main():
     pkg.init(0)
     rows = []
     for cfg in args.configs.split(","):
-        curve, group, logn = (int(x) for x in cfg.split(":"))
-        n = 1 << logn
+        curve, group, size = cfg.split(":")
+        curve, group = int(curve), int(group)
+        # "20": 2^20 points; "n3145727": that many (the concatenated set H | L | B1 of B::groth16_C at d = 2^20 - 1)
+        n = int(size[1:]) if size.startswith("n") else 1 << int(size)
+        logn = int(size) if not size.startswith("n") else float(np.log2(n))
         pts = pkg.synth_points(curve, group, 42, n)
         sc = pkg.synth_scalars(curve, 43, n)
         exp = pkg.point_to_affine(curve, group, pkg.synth_expected_msm(curve, group, 42, sc))

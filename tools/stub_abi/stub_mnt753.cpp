@@ -127,6 +127,7 @@ static void touch(uint64_t* v, size_t n) { volatile uint64_t s = 0; for (size_t 
 int mnt753_fft(mnt753_domain* d, int, uint64_t* v, void*) { if (!d || !v) return fail(MNT753_EINVAL, "fft: null"); touch(v, d->m); return 0; }
 int mnt753_divide_by_z_on_coset(mnt753_domain* d, uint64_t* v, void*) { if (!d || !v) return fail(MNT753_EINVAL, "divide_by_z: null"); touch(v, d->m); return 0; }
 int mnt753_vec_muleq(int, uint64_t* a, const uint64_t* b, size_t n, void*) { touch(a, n); touch(const_cast<uint64_t*>(b), n); return 0; }
+int mnt753_vec_scale(int, uint64_t* d, const uint64_t* s, const uint64_t* k, size_t n, void*) { touch(const_cast<uint64_t*>(s), n); touch(d, n); return k ? 0 : -2; }
 int mnt753_vec_subeq(int, uint64_t* a, const uint64_t* b, size_t n, void*) { touch(a, n); touch(const_cast<uint64_t*>(b), n); return 0; }
 int mnt753_compute_h(mnt753_domain* d, uint64_t* a, uint64_t* b, uint64_t* c, uint64_t* h, void*) {
   if (!d || !a || !b || !c || !h) return fail(MNT753_EINVAL, "compute_h: null");
