@@ -401,13 +401,15 @@ def main():
         n_local = hi - lo                       # pairs one launch of the dominant kernels processes on this rank
         achieved = ALGO_BYTES_PER_PAIR * n_local / (acc * 1e-3) / 1e9
         plan_c, windows = plan["window_bits"], plan["windows"]
-        levels = plan.get("pair_levels", 0)
+        regular_levels, irr_levels = plan.get("pair_levels", 0), plan.get("irr_levels", 0)
+        levels = regular_levels + irr_levels    # irregular levels: the same batched-affine addition on what the regular ones leave (no padding)
         # Montgomery products per sorted entry: an affine pair addition is 5 products + 1 squaring (0.76 of a product) including
         # the 3 of the simultaneous inversion, on 1/2, 1/4, ... of the entries; one divstep inversion (~94 products) per lane and
         # level over B = slots / 65536 lanes (at least 48); 11 per mixed addition on what is left
         slots = [windows * n_local / 2 ** l for l in range(1, levels + 1)]
         prod_per_entry = sum((5.76 + 94.0 / max(8.0, sl / 65536.0)) / 2 ** l for l, sl in zip(range(1, levels + 1), slots)) + 11.0 / 2 ** levels
-        kernel_name = "k_bucket_accumulate<Mnt4G1>" if levels == 0 else f"k_pair_level<Mnt4G1> x{levels} + k_bucket_accumulate<Mnt4G1>"
+        kernel_name = "k_bucket_accumulate<Mnt4G1>" if levels == 0 else (
+            f"k_pair_level<Mnt4G1> x{regular_levels}" + (f" + x{irr_levels} irregular" if irr_levels else "") + " + k_bucket_accumulate<Mnt4G1>")
         # PMC traffic of the same phase (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh); quoted only
         # while the kernel sources are the ones it was measured on
         traffic, traffic_info = None, None
@@ -453,7 +455,7 @@ def main():
                          "note": "bucket accumulation phase of one MSM (HIP events on the launch stream). `achieved` is ALGORITHMIC bytes / time as the "
                                  "contract asks; the phase is bound by the 753-bit multiplier (modmul_frac) and, in the first pairing level, by scattered "
                                  "table-row gathers (traffic_info.frac_of_hbm_peak), not by streaming",
-                         "pair_levels": levels, "products_per_entry": prod_per_entry,
+                         "pair_levels": regular_levels, "irregular_levels": irr_levels, "products_per_entry": prod_per_entry,
                          "modmul_per_s": prod_per_entry * windows * n_local / (acc * 1e-3), "modmul_peak_per_s": MODMUL_PEAK_PER_S,
                          "modmul_frac": prod_per_entry * windows * n_local / (acc * 1e-3) / MODMUL_PEAK_PER_S,
                          "mixed_addition_equivalents_per_s": windows * n_local / (acc * 1e-3)},

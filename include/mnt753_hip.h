@@ -132,6 +132,8 @@ int mnt753_msm_last_timing(float out_ms[5]);
 int mnt753_msm_last_plan(int out[4]);
 /* Levels of the batched-affine pairing pass the last G1 MSM ran before its accumulate kernel (0 = none). */
 int mnt753_msm_last_pair_levels(void);
+/* irregular pairing levels the last MSM ran behind the regular ones (csrc/msm_kernels.hip.h, "irregular levels") */
+int mnt753_msm_last_irr_levels(void);
 
 /* ---- small group operations on the host (O(1) work per proof) ------------------------------------ */
 /* replaces B::G1_add (hpp:32) */

@@ -63,6 +63,7 @@ def lib():
         "mnt753_msm_last_timing": (i, [C.POINTER(C.c_float)]),
         "mnt753_msm_last_plan": (i, [C.POINTER(C.c_int)]),
         "mnt753_msm_last_pair_levels": (i, []),
+        "mnt753_msm_last_irr_levels": (i, []),
         "mnt753_point_add": (i, [i, i, u64p, u64p, u64p]),
         "mnt753_point_scale": (i, [i, i, u64p, u64p, u64p]),
         "mnt753_point_to_affine": (i, [i, i, u64p, u64p]),
@@ -180,7 +181,7 @@ def msm_last_plan():
     t = (C.c_int * 4)()
     _check(lib().mnt753_msm_last_plan(t), "mnt753_msm_last_plan")
     return dict(window_bits=t[0], windows=t[1], window_table=bool(t[2]), entries_per_lane=t[3],
-                pair_levels=int(lib().mnt753_msm_last_pair_levels()))
+                pair_levels=int(lib().mnt753_msm_last_pair_levels()), irr_levels=int(lib().mnt753_msm_last_irr_levels()))
 
 
 def point_add(curve, group, a, b):

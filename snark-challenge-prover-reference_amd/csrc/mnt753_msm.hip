@@ -11,6 +11,7 @@ int g_window_bits_override = 0;
 float g_last_timing[5] = {0, 0, 0, 0, 0};
 int g_last_plan[4] = {0, 0, 0, 0};
 int g_last_pair_levels = 0;
+int g_last_irr_levels = 0;
 int g_point_cus = 256;
 }
 using namespace mnt753;
@@ -145,6 +146,7 @@ int mnt753_msm_last_timing(float out_ms[5]) {
 }
 
 int mnt753_msm_last_pair_levels(void) { return g_last_pair_levels; }
+int mnt753_msm_last_irr_levels(void) { return g_last_irr_levels; }
 
 int mnt753_msm_last_plan(int out[4]) {
   if (!out) return set_error(MNT753_EINVAL, "msm_last_plan: null");

@@ -28,6 +28,7 @@ extern int g_window_bits_override;
 extern float g_last_timing[5];
 extern int g_last_plan[4];
 extern int g_last_pair_levels;
+extern int g_last_irr_levels;
 extern int g_point_cus;
 }
 namespace {
@@ -46,13 +47,16 @@ int pick_window_bits(size_t n) {
   return best;
 }
 
-// window size when all windows share one bucket set: N*W bucket adds + one reduction of 2^(c-1) buckets
-int pick_precomp_bits(size_t n) {
+// window size when all windows share one bucket set: N*W bucket adds + one reduction of 2^(c-1) buckets.  A bucket of the reduction
+// costs `bucket_weight` additions of the accumulation: 4 for G1, 8 for the extension-field groups, whose reduction runs the general
+// addition against batched-affine accumulation (2^20 points, profiles/r03/window_width_sweep.txt: G1 25.45 / 25.53 / 26.74 ms at
+// c = 19 / 20 / 21, Fq2 G2 69.45 / 70.16 / 74.31 ms).
+int pick_precomp_bits(size_t n, double bucket_weight = 4.0) {
   if (const char* e = getenv("MNT753_MSM_PRE_C")) { int v = atoi(e); if (v >= 2 && v <= 24) return v; }
   int best = 2; double best_cost = 1e300;
   for (int c = 2; c <= 22; ++c) {
     double W = (754 + c - 1) / c;
-    double cost = W * (double)n + 4.0 * (double)(1u << (c - 1)) * 14.0 / 11.0;
+    double cost = W * (double)n + bucket_weight * (double)(1u << (c - 1)) * 14.0 / 11.0;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
@@ -100,6 +104,7 @@ MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   p.L = L;
   p.n_chunks = p.n_buckets / L;
   p.pair_levels = 0;   // filled in by the caller (plan_for): depends on the group and on the workspace the base set could get
+  p.irr_levels = 0;
   return p;
 }
 
@@ -127,9 +132,10 @@ int point_lanes() {
   else return use_split_acc<C>() ? CS::F::LANES : 1;
 }
 void free_pair_ws(mnt753_bases* b) {
-  void* ptrs[] = {b->d_pair_ws, b->d_fix, b->d_gen, b->d_pairpts[0], b->d_pairpts[1], b->d_sorted2};
+  void* ptrs[] = {b->d_pair_ws, b->d_fix, b->d_gen, b->d_pairpts[0], b->d_pairpts[1], b->d_sorted2, b->d_irr_offs[0], b->d_irr_offs[1], b->d_irr_src, b->d_irr_blocks};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   b->d_pair_ws = b->d_fix = b->d_gen = b->d_sorted2 = nullptr;
+  b->d_irr_offs[0] = b->d_irr_offs[1] = b->d_irr_src = b->d_irr_blocks = nullptr;
   b->d_pairpts[0] = b->d_pairpts[1] = nullptr;
   b->pair_cap = 0;
   b->pair_buckets = 0;
@@ -218,7 +224,7 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   if (const char* e = getenv("MNT753_MSM_PRECOMP")) want_table = atoi(e) != 0 && n > 0;
   int pc = 0, pW = 1;
   if (want_table) {
-    pc = pick_precomp_bits(n);
+    pc = pick_precomp_bits(n, C::F::DEG == 1 ? 4.0 : 8.0);
     pW = (754 + pc - 1) / pc;
     if ((uint64_t)pW * n >= 0x7fffffffull) { want_table = false; pc = 0; pW = 1; }   // row index must fit 31 bits
   }
@@ -306,6 +312,9 @@ void horner_host(const uint64_t* wire_pts, int n_sets, int c, uint64_t* out) {
 // Lanes per level: one round of the machine at one wave per SIMD, every lane in use down to batches of PAIR_MIN_B additions per
 // inversion.  MNT753_PAIR_LANES / MNT753_PAIR_MINB are development overrides.
 inline uint32_t pair_env(const char* name, uint32_t dflt) { const char* e = getenv(name); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; }
+#ifndef MNT753_IRR_DEFAULT
+#define MNT753_IRR_DEFAULT 1
+#endif
 #define PAIR_MAX_LANES pair_env("MNT753_PAIR_LANES", 65536u)
 #define PAIR_MIN_B pair_env("MNT753_PAIR_MINB", 8u)
 // Levels of the pairing pass for an MSM with `entries` sorted entries, from the one-GPU slice sweep of round 3
@@ -332,6 +341,29 @@ int pair_levels(uint64_t entries) {
     return 0;
   }
 }
+// Irregular levels behind the regular ones (k_pair_level<.., IRR>, msm_kernels.hip.h): MNT753_MSM_IRR=<levels> overrides, 0 turns
+// them off.  A level is worth its inversion (one per lane, ~0.3 ms of wave time whatever the batch) while it still has a batch per
+// lane, and worth anything only while buckets hold more than a couple of slots; from the one-GPU sweep of round 3
+// (profiles/r03/irregular_levels_sweep.txt): at least 16 output slots per lane for the base fields, 10 for the lane-split ones (their
+// additions cost three times as much against the same inversion), at most three levels.
+//   2^20 points:  G1 25.7 -> 25.2 ms with two levels, Fq2 G2 70.0 -> 66.5 ms with three;  3 * 2^20 G1 points (H | L | B1): 66.3 -> 62.8.
+template <class C>
+int irr_levels_for(uint64_t entries, int regular_levels, uint32_t n_buckets) {
+  if (const char* e = getenv("MNT753_MSM_IRR")) { int v = atoi(e); return v < 0 ? 0 : (v > 8 ? 8 : v); }
+  if (!MNT753_IRR_DEFAULT) return 0;
+  const double lanes = (double)std::min<uint32_t>(machine_lanes(C::F::LANES), C::F::LANES == 3 ? PAIR_MAX_LANES / 3u : PAIR_MAX_LANES / (uint32_t)C::F::LANES);
+  const double min_batch = C::F::LANES == 1 ? 16.0 : 10.0;
+  double slots = (double)entries / (double)(1u << regular_levels) + 0.5 * n_buckets;
+  int k = 0;
+  while (k < 3) {
+    if (slots <= 2.2 * n_buckets) break;                 // hardly a pair left per bucket
+    const double out = 0.5 * slots + 0.25 * n_buckets;   // half the buckets keep an odd leftover
+    if (out < min_batch * lanes) break;
+    slots = out;
+    ++k;
+  }
+  return k;
+}
 // level-1 slots of the worst case of plan p: (W n + n_buckets (2^L - 1)) / 2
 inline uint64_t pair_cap1(const MsmPlan& p, size_t n) {
   return ((uint64_t)p.W * n + (uint64_t)p.n_buckets * (((uint64_t)1 << p.pair_levels) - 1)) / 2;
@@ -350,8 +382,13 @@ int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p, size_t n) {
     // rows of a level: row-major (last level, 224 B x DEG per slot) or four blocked planes (same bytes + rounding per plane)
     const size_t slack = 4 * 64 * 7 * 16 * 2;
     HIP_TRY(hipMalloc(&b->d_pairpts[0], sizeof(uint32_t) * aff_words<V>() * capA + slack * V::F::DEG));             // levels 1, 3, 5
-    HIP_TRY(hipMalloc(&b->d_pairpts[1], sizeof(uint32_t) * aff_words<V>() * (capA / 2 + 1) + slack * V::F::DEG));   // levels 2, 4, 6
+    // (an irregular level writes at most half its input plus one slot per bucket: the buckets' worth of room covers it at any depth)
+    HIP_TRY(hipMalloc(&b->d_pairpts[1], sizeof(uint32_t) * aff_words<V>() * (capA / 2 + nbA + 1) + slack * V::F::DEG));   // levels 2, 4, 6
     HIP_TRY(hipMalloc(&b->d_sorted2, sizeof(uint32_t) * capA));                                 // entry list of the last level
+    HIP_TRY(hipMalloc(&b->d_irr_offs[0], sizeof(uint32_t) * (nbA + 1)));
+    HIP_TRY(hipMalloc(&b->d_irr_offs[1], sizeof(uint32_t) * (nbA + 1)));
+    HIP_TRY(hipMalloc(&b->d_irr_src, sizeof(uint32_t) * (capA / 2 + nbA + 64)));
+    HIP_TRY(hipMalloc(&b->d_irr_blocks, sizeof(uint32_t) * (nbA / IRR_BLOCK + 4)));
     HIP_TRY(hipMalloc(&b->d_pair_ws, 16 * blk_quads((uint64_t)capA * V::F::LANES + 64)));       // one prefix product per slot (blocked)
     // D: the group generator in device form (wire constant -> k_bases_to_internal)
     uint32_t* wire = nullptr; uint8_t* inf = nullptr;
@@ -383,6 +420,12 @@ int pair_levels_for(uint64_t entries) {
   if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return pair_levels<CS>(entries); }
   return pair_levels<C>(entries);
 }
+template <class C>
+int irr_levels_for_group(uint64_t entries, int regular_levels, uint32_t n_buckets) {
+  using CS = typename SplitOf<C>::type;
+  if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return irr_levels_for<CS>(entries, regular_levels, n_buckets); }
+  return irr_levels_for<C>(entries, regular_levels, n_buckets);
+}
 // plan of an MSM over n points of base set b: make_plan + the pairing levels this group / base set runs with
 template <class C>
 MsmPlan plan_for(const mnt753_bases* b, size_t n) {
@@ -395,6 +438,7 @@ MsmPlan plan_for(const mnt753_bases* b, size_t n) {
   if (point_lanes<C>() == 1 && C::F::DEG == 1 && (uint64_t)p.W * std::max<uint64_t>(b->n, n) * 14u >= 0xffffffffull) p.pair_levels = 0;
   // every field: blocked indices of level-1 slots (7 uint4 per element and lane) are 32-bit in the level kernels
   if (p.pair_levels > 0 && pair_cap1(p, n) * (uint64_t)point_lanes<C>() * 7u >= 0xffffff00ull) p.pair_levels = 0;
+  p.irr_levels = p.pair_levels > 0 ? irr_levels_for_group<C>((uint64_t)p.W * n, p.pair_levels, p.n_buckets) : 0;
   return p;
 }
 template <class V, class C>
@@ -410,11 +454,22 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
     const uint4* src_planes = nullptr;
     size_t src_stride = 0;
     const uint32_t* last_rows = nullptr;
+    // irregular levels behind the regular ones, as many as the ping-pong row buffers hold in the worst case (each writes at most half
+    // its input plus one slot per bucket)
+    int irr = p.irr_levels;
+    {
+      uint64_t c = cap >> levels;
+      for (int k = 1; k <= irr; ++k) {
+        c = c / 2 + p.n_buckets;
+        const uint64_t room = ((levels + k - 1) & 1) ? b->pair_cap / 2 + b->pair_buckets : b->pair_cap;
+        if (c > room || c > b->pair_cap / 2 + b->pair_buckets + 64) { irr = k - 1; break; }   // rows of the level, source words
+      }
+    }
     for (int l = 1; l <= levels; ++l) {
       cap /= 2;                                 // worst-case slots of this level (the kernel reads the actual count from offsG)
       const uint32_t lanes = (uint32_t)std::min<uint64_t>(max_lanes, (cap + min_B - 1) / min_B);
       uint32_t* out = b->d_pairpts[(l - 1) & 1];
-      const int first = l == 1, last = l == levels;
+      const int first = l == 1, last = l == levels && irr == 0;
       // planes of a level that feeds another one: (x | y) x (even | odd slot), each holding cap / 2 slots, blocked
       const size_t out_stride = blk_quads((cap / 2 + 1) * (uint64_t)V::F::LANES + 64);
 #define MNT753_PAIR_LAUNCH(FST, LST)                                                                                                         \
@@ -452,6 +507,39 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
       src_stride = out_stride;
       last_rows = out;
     }
+    // irregular levels: bucket offsets of their own (the regular levels' final slots are the groups offsG counts)
+    const uint32_t* offs_acc = b->d_offsets;
+    for (int k = 1; k <= irr; ++k) {
+      const int l = levels + k;
+      const uint32_t* offs_in = offs_acc;
+      uint32_t* offs_out = b->d_irr_offs[k & 1];
+      const uint32_t n_blocks = (p.n_buckets + IRR_BLOCK - 1) / IRR_BLOCK;
+      hipLaunchKernelGGL(k_irr_count, dim3(n_blocks), dim3(IRR_BLOCK), 0, st, offs_in, p.n_buckets, b->d_irr_blocks);
+      hipLaunchKernelGGL(k_irr_scan, dim3(1), dim3(1024), 0, st, b->d_irr_blocks, n_blocks);
+      hipLaunchKernelGGL(k_irr_fill, dim3(n_blocks), dim3(IRR_BLOCK), 0, st, offs_in, p.n_buckets, b->d_irr_blocks, n_blocks, offs_out, b->d_irr_src);
+      cap = cap / 2 + p.n_buckets;               // worst case: every bucket keeps an odd leftover
+      const uint32_t lanes = (uint32_t)std::min<uint64_t>(max_lanes, (cap + min_B - 1) / min_B);
+      uint32_t* out = b->d_pairpts[(l - 1) & 1];
+      const size_t out_stride = blk_quads((cap / 2 + 1) * (uint64_t)V::F::LANES + 64);
+#define MNT753_IRR_LAUNCH(LST)                                                                                                               \
+  do {                                                                                                                                      \
+    static std::atomic<uint32_t> lds_set{0};                                                                                                \
+    const uint32_t dev_bit = 1u << (b->device & 31);                                                                                        \
+    if (!(lds_set.load(std::memory_order_acquire) & dev_bit)) {                                                                             \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_level<V, false, LST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS_BYTES)); \
+      lds_set.fetch_or(dev_bit, std::memory_order_release);                                                                                 \
+    }                                                                                                                                       \
+    hipLaunchKernelGGL((k_pair_level<V, false, LST, true>), dim3(blocks_for<typename V::F>(lanes)), dim3(256), PAIR_LDS_BYTES, st, d_aff, b->d_sorted, src_planes, \
+                       src_stride, offs_out, p.n_buckets, 0u, out, b->d_sorted2, reinterpret_cast<uint4*>(out), out_stride,                  \
+                       reinterpret_cast<uint4*>(b->d_pair_ws), min_B, lanes, b->d_gen, b->d_fix, b->d_irr_src);                              \
+  } while (0)
+      if (k == irr) MNT753_IRR_LAUNCH(true); else MNT753_IRR_LAUNCH(false);
+#undef MNT753_IRR_LAUNCH
+      src_planes = reinterpret_cast<const uint4*>(out);
+      src_stride = out_stride;
+      last_rows = out;
+      offs_acc = offs_out;
+    }
     const uint32_t* src = last_rows;
     // accumulate over at most `cap` entries: one round of the machine
     const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, machine_lanes(V::F::LANES));
@@ -466,7 +554,7 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
         acc_lds_set.fetch_or(dev_bit, std::memory_order_release);
       }
       hipLaunchKernelGGL((k_bucket_accumulate<V, true>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), acc_lds, st, src, b->d_sorted2,
-                         b->d_offsets, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
+                         offs_acc, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
     }
     *acc_lanes = lanes_acc;
     return 0;
@@ -486,6 +574,7 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
   const int n_pair_levels = p.pair_levels;
   uint32_t acc_lanes = p.n_lanes;   // lanes the accumulate kernel ran with (= edge slots / 2)
   g_last_pair_levels = n_pair_levels;
+  g_last_irr_levels = n_pair_levels > 0 ? p.irr_levels : 0;
   if (n_pair_levels > 0) {
     if (int rc = pair_and_accumulate<V, C>(p, n, st, d_aff, b, &acc_lanes)) return rc;
   } else {

@@ -437,6 +437,9 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
   const uint32_t t = logical_lane<typename C::F>();
   if (t >= n_lanes) return;
   const uint32_t total = offsets[n_buckets];
+  // BLOCKED (behind the pairing levels): the host only knows the worst case of the list the levels leave; every lane walks its
+  // entries one mixed addition after the other, so the kernel's time is the length of a lane's share -- taken from the actual total
+  if constexpr (BLOCKED) T = max((total + n_lanes - 1u) / n_lanes, min(T, 8u));
   uint64_t e0 = (uint64_t)t * T;
   if (e0 >= total) {
     edge_bucket[2 * t] = EDGE_NONE;
@@ -724,18 +727,95 @@ __device__ __forceinline__ uint32_t fp_from_lds(Fp<M>& r, const uint4* p, uint32
   return flag;
 }
 
+// ---- irregular levels ---------------------------------------------------------------------------------------------------------
+// The regular tree pads every bucket to 2^L entries, which is why it stops at L = 3 (76 entries per bucket at 2^20 points: 4.6 % of
+// the level-1 slots are padding with 8-entry groups, 10 % with 16, 20 % with 32) and leaves ~10 slots per bucket to the projective
+// accumulate -- 11 products an addition against 6.  An IRREGULAR level halves what a previous level left WITHOUT padding: a bucket
+// with g slots gets ceil(g / 2) output slots, output slot o' of bucket b adds the input slots
+//       s1 = offs_in[b] + 2 (o' - offs_out[b])   and   s1 + 1   (an odd leftover is copied),
+// and the only irregularity the level kernel sees is one word per output slot, src[o'] = s1 | (leftover << 31), prepared by the
+// three small kernels below (count / scan / fill).  The planes keep their layout (slot s in plane s & 1 at element s >> 1), so a
+// wave's 64 consecutive output slots still read two runs of consecutive elements, broken only where a bucket with an odd count ends.
+constexpr uint32_t IRR_BLOCK = 256;   // buckets per workgroup of the count / fill kernels
+static __global__ void __launch_bounds__(IRR_BLOCK) k_irr_count(const uint32_t* __restrict__ offs_in, uint32_t n_buckets, uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t part[IRR_BLOCK / 64];
+  const uint32_t b = blockIdx.x * IRR_BLOCK + threadIdx.x;
+  uint32_t c = b < n_buckets ? (offs_in[b + 1] - offs_in[b] + 1u) >> 1 : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// exclusive scan of the block sums in place (one workgroup; n_blocks <= a few thousand), total behind them
+static __global__ void __launch_bounds__(1024) k_irr_scan(uint32_t* __restrict__ block_sums, uint32_t n_blocks) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_blocks; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n_blocks ? block_sums[i] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if ((threadIdx.x & 63u) >= (uint32_t)d) x += y; }
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    uint32_t before = carry;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+    if (i < n_blocks) block_sums[i] = before + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_sums[n_blocks] = carry;
+}
+static __global__ void __launch_bounds__(IRR_BLOCK) k_irr_fill(const uint32_t* __restrict__ offs_in, uint32_t n_buckets, const uint32_t* __restrict__ block_sums,
+                                                              uint32_t n_blocks, uint32_t* __restrict__ offs_out, uint32_t* __restrict__ src) {
+  __shared__ uint32_t out0[IRR_BLOCK + 1], in0[IRR_BLOCK + 1], wsum[IRR_BLOCK / 64];
+  const uint32_t b = blockIdx.x * IRR_BLOCK + threadIdx.x;
+  const uint32_t lo = b < n_buckets ? offs_in[b] : offs_in[n_buckets];
+  const uint32_t hi = b < n_buckets ? offs_in[b + 1] : lo;
+  const uint32_t c = (hi - lo + 1u) >> 1;
+  uint32_t x = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if ((threadIdx.x & 63u) >= (uint32_t)d) x += y; }
+  if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = x;
+  __syncthreads();
+  uint32_t before = block_sums[blockIdx.x];
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+  const uint32_t o0 = before + x - c;
+  out0[threadIdx.x] = o0;
+  in0[threadIdx.x] = lo;
+  if (threadIdx.x == IRR_BLOCK - 1) { out0[IRR_BLOCK] = o0 + c; in0[IRR_BLOCK] = hi; }
+  if (b < n_buckets) offs_out[b] = o0;
+  if (b == n_buckets - 1u) offs_out[n_buckets] = block_sums[n_blocks];
+  __syncthreads();
+  // the output slots of the workgroup's buckets, all threads together (a bucket of any length costs its share, no more)
+  const uint32_t O0 = out0[0], O1 = out0[IRR_BLOCK];
+  for (uint32_t o = O0 + threadIdx.x; o < O1; o += IRR_BLOCK) {
+    uint32_t l = 0, h = IRR_BLOCK - 1u;              // largest i with out0[i] <= o (empty buckets share their successor's value)
+    while (l < h) { const uint32_t mid = (l + h + 1u) >> 1; if (out0[mid] <= o) l = mid; else h = mid - 1u; }
+    const uint32_t s1 = in0[l] + 2u * (o - out0[l]);
+    src[o] = s1 | ((s1 + 1u == in0[l + 1u]) ? 0x80000000u : 0u);
+  }
+}
+
 // first: sources are rows of `src_rows` (the window table, row-major) named by the padded entry list; otherwise the four
 //        planes of the previous level at src_planes (plane stride src_stride uint4s).
+// IRR:   (not first) an irregular level: offsG holds the level's OUTPUT offsets (shift = 0) and irr_src one word per output slot.
 // last:  besides the four planes at out_planes (stride out_stride) the level writes the entry list out_sorted (slot o -> row o
 //        of the planes as (o << 1) | sign) that the accumulate kernel (BLOCKED instantiation) reads.
-template <class C, bool first, bool last>
+template <class C, bool first, bool last, bool IRR = false>
 __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restrict__ src_rows,
                                                       const uint32_t* __restrict__ entries, const uint4* __restrict__ src_planes,
                                                       size_t src_stride, const uint32_t* __restrict__ offsG, uint32_t n_buckets,
                                                       uint32_t shift, uint32_t* __restrict__ out_rows, uint32_t* __restrict__ out_sorted,
                                                       uint4* __restrict__ out_planes, size_t out_stride, uint4* __restrict__ prefix_ws,
                                                       uint32_t min_B, uint32_t n_lanes,
-                                                      const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count) {
+                                                      const uint32_t* __restrict__ gen, uint32_t* __restrict__ fix_count,
+                                                      const uint32_t* __restrict__ irr_src = nullptr) {
+  static_assert(!(IRR && first), "the first level reads the table through the entry list");
   using F = typename C::F;
   using E = typename F::E;                 // a single Fp: base field, or one component per lane of a lane-split field
   constexpr int M = F::MOD;
@@ -791,9 +871,25 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   };
   // LDS-DMA instruction k of the rows of iteration `it` (entries already in ent_img[buf]); xonly = x coordinates only (forward
   // sweep).  first: 2 * NS * rq quads in image order, 64 per instruction; later levels: one instruction per (plane, quad).
-  auto issue_row_piece = [=](uint32_t it, uint32_t buf, uint32_t k, auto xonly_c, uint4* im) __attribute__((always_inline)) {
+  // IRR: the per-lane part (uint4 units, plane of the slot's parity included) of the addresses of the two input slots a word of
+  // irr_src names; an odd leftover names its one slot twice
+  auto irr_bases = [=](uint32_t sw, uint32_t& va, uint32_t& vb) __attribute__((always_inline)) {
+    const uint32_t s1 = sw & 0x7fffffffu, s2 = s1 + ((sw >> 31) ^ 1u);
+    va = (s1 & 1u) * (uint32_t)src_stride + (uint32_t)blk_index((s1 >> 1) * LN + comp);
+    vb = (s2 & 1u) * (uint32_t)src_stride + (uint32_t)blk_index((s2 >> 1) * LN + comp);
+  };
+  // IRR: the word of the slot this thread (or, for idle lanes, the wave's first lane) has at iteration `it`
+  auto irr_word = [=](uint32_t it) __attribute__((always_inline)) {
+    return irr_src[min(it * NLe + (lane_on ? t : t0w), S - 1u)];
+  };
+  auto issue_row_piece = [=](uint32_t it, uint32_t buf, uint32_t k, auto xonly_c, uint4* im, uint32_t sw = 0u) __attribute__((always_inline)) {
     constexpr bool xonly = decltype(xonly_c)::value;
-    if constexpr (first) {
+    if constexpr (IRR) {
+      uint32_t va, vb;
+      irr_bases(sw, va, vb);
+      const uint32_t pl = k / 7u, q = k - pl * 7u;        // image planes: x1 | x2 | y1 | y2
+      glds16(src_planes + (size_t)(pl & 2u) * src_stride + (size_t)q * 64 + ((pl & 1u) ? vb : va), im + k * 64u);
+    } else if constexpr (first) {
       constexpr uint32_t rq = xonly ? XQ : RQ;
       constexpr uint32_t total = 2u * NS * rq;
       const uint32_t i = min(64u * k + lane, total - 1u);
@@ -811,10 +907,10 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   };
   constexpr uint32_t ROW_PIECES_X = first ? (2u * NS * XQ + 63u) / 64u : 14u;
   constexpr uint32_t ROW_PIECES = first ? (2u * NS * RQ + 63u) / 64u : 28u;
-  auto issue_rows = [=](uint32_t it, uint32_t buf, auto xonly_c, uint4* im) __attribute__((always_inline)) {
+  auto issue_rows = [=](uint32_t it, uint32_t buf, auto xonly_c, uint4* im, uint32_t sw = 0u) __attribute__((always_inline)) {
     constexpr uint32_t n = decltype(xonly_c)::value ? ROW_PIECES_X : ROW_PIECES;
 #pragma unroll
-    for (uint32_t k = 0; k < n; ++k) issue_row_piece(it, buf, k, xonly_c, im);
+    for (uint32_t k = 0; k < n; ++k) issue_row_piece(it, buf, k, xonly_c, im, sw);
   };
   // first level: the table offsets (uint4 units) of this lane's pieces of one slot, all read out of ent_img[buf] in one go.
   // A ds_read + s_waitcnt lgkmcnt(0) in front of EVERY LDS-DMA instruction cost a quarter of the level (the LDS queue is
@@ -867,27 +963,33 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   constexpr uint32_t XIMG = PAIR_IMG_QUADS / 2u;          // one x-only image (14 pieces of 64 quads)
   static_assert(ROW_PIECES_X * 64u <= XIMG, "x image");
   // x image of slot `it` -> half (it & 1) of the row image; first level: offsets from the entries in ent_img[it & 3]
-  auto issue_x = [=](uint32_t it) __attribute__((always_inline)) {
+  auto issue_x = [=](uint32_t it, uint32_t sw = 0u) __attribute__((always_inline)) {
     uint4* im = img + (it & 1u) * XIMG;
-    issue_rows(it, it & 3u, std::true_type{}, im);
+    issue_rows(it, it & 3u, std::true_type{}, im, sw);
   };
   constexpr uint32_t AH = MNT753_PAIR_FWD_AHEAD;          // slots between the issue of an x image and its use
+  static_assert(!IRR || AH == 1u, "irregular levels fetch one slot ahead");
+  // IRR: the source words of this slot and the next (the one after that is loaded while this slot's product runs)
+  uint32_t sw_cur = 0u, sw_nxt = 0u;
+  if constexpr (IRR) { sw_cur = irr_word(0); sw_nxt = irr_word(min(1u, n_it - 1u)); }
   if constexpr (first) {
     issue_entries(0, 0);
     issue_entries(min(1u, n_it - 1u), 1);
     if constexpr (AH == 2u) issue_entries(min(2u, n_it - 1u), 2);
     wait_vm0();
   }
-  issue_x(0);
+  issue_x(0, sw_cur);
   if constexpr (AH == 2u) { if (n_it > 1u) issue_x(1); }
   for (uint32_t it = 0; it < n_it; ++it) {
     const uint32_t o = it * NLe + t;
     const bool on = lane_on && o < S;
     uint32_t f0, f1;
+    uint32_t sw_nn = 0u;
     // the image of this slot is complete; the 14 loads of the next slot's image (issued after everything else of the previous
     // iteration) may stay in flight -- vmcnt counts in issue order
     if (AH == 2u && it + 1u < n_it) wait_vm14(); else wait_vm0();
     read_rows(it & 3u, std::true_type{}, img + (it & 1u) * XIMG, f0, f1, x1, y1, x2, y2);
+    if constexpr (IRR) { if (sw_cur >> 31) f1 = PF_EMPTY; }   // odd leftover: the second operand is the first one again
     const bool ahead = it + AH < n_it;
     uint32_t off[ROW_PIECES];
     if constexpr (PRELOAD) { if (ahead) load_row_offsets((it + AH) & 3u, std::true_type{}, off); }
@@ -901,10 +1003,11 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
 #pragma unroll
         for (uint32_t k = 0; k < ROW_PIECES_X; ++k) glds16(table + off[k], im + 64u * k);
       } else {
-        issue_rows(it + AH, (it + AH) & 3u, std::true_type{}, im);
+        issue_rows(it + AH, (it + AH) & 3u, std::true_type{}, im, sw_nxt);
       }
     };
     if constexpr (AH == 1u) { if (ahead) issue_ahead(off); }
+    if constexpr (IRR) { if (it + 2u < n_it) sw_nn = irr_word(it + 2u); }   // in flight during this slot's product
     uint32_t kind;
     if (!on || (f0 & PF_EMPTY)) kind = PK_EMPTY;
     else if (f1 & PF_EMPTY) kind = PK_SINGLE;
@@ -925,6 +1028,10 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
           const uint2 e = reinterpret_cast<const uint2*>(entries)[o];
           fp_load(y1, src_rows + (size_t)(e.x & 0x7fffffffu) * AW + EW + cw);
           fp_load(y2, src_rows + (size_t)(e.y & 0x7fffffffu) * AW + EW + cw);
+        } else if constexpr (IRR) {
+          const uint32_t s1 = sw_cur & 0x7fffffffu, s2 = s1 + 1u;
+          (void)fp_load_blk(y1, src_planes + (2 + (s1 & 1u)) * src_stride, (s1 >> 1) * LN + comp);
+          (void)fp_load_blk(y2, src_planes + (2 + (s2 & 1u)) * src_stride, (s2 >> 1) * LN + comp);
         } else {
           (void)fp_load_blk(y1, src_planes + 2 * src_stride, o * LN + comp);
           (void)fp_load_blk(y2, src_planes + 3 * src_stride, o * LN + comp);
@@ -945,6 +1052,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       if constexpr (LAZY) F::mul_s(tmp, run, den); else F::mul(tmp, run, den);
       run = tmp;
     }
+    if constexpr (IRR) { sw_cur = sw_nxt; sw_nxt = sw_nn; }
   }
   E inv;
   PAIR_T(tc1);
@@ -954,16 +1062,16 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   // ---- backward: individual inverses and the sums (highest slot of the wave first)
   // piece `idx` of the LDS-DMA of iteration `it`: ROW_PIECES row pieces, then the 7 quads of the prefix product
   constexpr uint32_t BWD_PIECES = ROW_PIECES + 7u;
-  auto issue_bwd_piece = [=](uint32_t it, uint32_t buf, uint32_t idx) __attribute__((always_inline)) {
-    if (idx < ROW_PIECES) issue_row_piece(it, buf, idx, std::false_type{}, img);
+  auto issue_bwd_piece = [=](uint32_t it, uint32_t buf, uint32_t idx, uint32_t sw = 0u) __attribute__((always_inline)) {
+    if (idx < ROW_PIECES) issue_row_piece(it, buf, idx, std::false_type{}, img, sw);
     else if (idx < BWD_PIECES) {
       const uint32_t o = min(it * NLe + (lane_on ? t : t0w), S - 1u);
       const uint32_t q = idx - ROW_PIECES;
       glds16(prefix_ws + blk_index(o * LN + comp) + (size_t)q * 64, pre_img + q * 64u);
     }
   };
-  auto issue_bwd = [=](uint32_t it, uint32_t buf) __attribute__((always_inline)) {
-    for (uint32_t idx = 0; idx < BWD_PIECES; ++idx) issue_bwd_piece(it, buf, idx);
+  auto issue_bwd = [=](uint32_t it, uint32_t buf, uint32_t sw = 0u) __attribute__((always_inline)) {
+    for (uint32_t idx = 0; idx < BWD_PIECES; ++idx) issue_bwd_piece(it, buf, idx, sw);
   };
   wait_vm0();                                            // the forward sweep's own stores (prefix products, kinds) are complete
   if constexpr (first) {
@@ -971,7 +1079,9 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     wait_vm0();
     issue_entries(n_it > 1u ? n_it - 2u : 0u, 1);
   }
-  issue_bwd(n_it - 1u, 0);
+  // IRR: the source words of this slot and of the next one down (the one after that is loaded during this slot's products)
+  if constexpr (IRR) { sw_cur = irr_word(n_it - 1u); sw_nxt = irr_word(n_it > 1u ? n_it - 2u : 0u); }
+  issue_bwd(n_it - 1u, 0, sw_cur);
   wait_vm0();
   for (uint32_t n = 0; n < n_it; ++n) {
     const uint32_t it = n_it - 1u - n;
@@ -979,12 +1089,17 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     const bool on = lane_on && o < S;
     uint32_t f0, f1;
     E pre;
+    uint32_t sw_nn = 0u;
+    if constexpr (IRR) { if (it >= 2u) sw_nn = irr_word(it - 2u); }
     read_rows(n & 1u, std::false_type{}, img, f0, f1, x1, y1, x2, y2);
+    if constexpr (IRR) { if (sw_cur >> 31) f1 = PF_EMPTY; }
     const uint32_t kflag = fp_from_lds(pre, pre_img + lane, 64u);
     const uint32_t kind = on ? kflag : (uint32_t)PK_EMPTY;
     const bool more = n + 1u < n_it;
     // blocked index (uint4 units) of the next slot's element: the per-lane part of the addresses of its planes and prefix product
     const uint32_t vb_next = more ? (uint32_t)blk_index(min((it - 1u) * NLe + (lane_on ? t : t0w), S - 1u) * LN + comp) : 0u;
+    uint32_t va_irr = 0u, vb_irr = 0u;        // IRR: per-lane parts of the next slot's two input slots
+    if constexpr (IRR) { if (more) irr_bases(sw_nxt, va_irr, vb_irr); }
     uint32_t off[ROW_PIECES];
     if constexpr (PRELOAD_BWD && !MNT753_PAIR_OFF_PER_STEP) { if (more) load_row_offsets((n + 1u) & 1u, std::false_type{}, off); }
     wait_lgkm0();
@@ -1060,6 +1175,11 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
                   uint32_t k = idx;
                   asm volatile("" : "+s"(k));
                   issue_row_piece(it - 1u, (n + 1u) & 1u, k, std::false_type{}, img);
+                } else if constexpr (IRR) {
+                  const uint32_t pl = idx / 7u, q = idx - pl * 7u;
+                  uint32_t o = (pl & 1u) ? vb_irr : va_irr;
+                  asm volatile("" : "+v"(o));
+                  glds16(src_planes + (size_t)(pl & 2u) * src_stride + (size_t)q * 64 + o, img + 64u * idx);
                 } else {
                   const uint32_t pl = idx / 7u, q = idx - pl * 7u;
                   uint32_t o = vb;
@@ -1166,6 +1286,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
 #ifdef MNT753_PAIR_TIMING
     tw_d += __builtin_readcyclecounter() - tst0;
 #endif
+    if constexpr (IRR) { sw_cur = sw_nxt; sw_nxt = sw_nn; }
   }
   PAIR_T(tc3);
   PAIR_ACC(0, tc0, tc1); PAIR_ACC(1, tc1, tc2); PAIR_ACC(2, tc2, tc3); PAIR_ACC(3, 0ull, 1ull);

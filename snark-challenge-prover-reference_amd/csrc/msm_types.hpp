@@ -16,6 +16,7 @@ struct MsmPlan {
   int pre;            // 1: all windows share one bucket set (precomputed window multiples)
   uint32_t n_sets;    // bucket sets: W, or 1 with the table
   int pair_levels;    // batched-affine pairing levels ahead of the accumulate (0 = none): buckets are padded to 2^pair_levels entries
+  int irr_levels;     // irregular levels behind them (no padding: ceil(g / 2) slots for a bucket with g), 0 = none
 };
 }  // namespace mnt753
 
@@ -44,6 +45,7 @@ struct mnt753_bases {
   // pairing levels (batched affine additions ahead of the accumulate): grow-only buffers
   uint32_t *d_pair_ws = nullptr, *d_fix = nullptr, *d_gen = nullptr;   // prefix products, cancellation counts per bucket, the stand-in point D
   uint32_t *d_pairpts[2] = {nullptr, nullptr}, *d_sorted2 = nullptr;    // rows of the levels (ping-pong), entry list of the last level
+  uint32_t *d_irr_offs[2] = {nullptr, nullptr}, *d_irr_src = nullptr, *d_irr_blocks = nullptr;   // irregular levels: bucket offsets (ping-pong), source words, block sums
   size_t pair_cap = 0;   // level-1 slots the pairing buffers hold
   size_t pair_buckets = 0;   // buckets d_fix holds
   size_t sorted_cap = 0;     // entries d_sorted holds (padded layout: W*n + n_buckets*(2^levels - 1))

@@ -167,6 +167,8 @@ def test_full_size_2pow20_g1_mnt4753(gpu):
     bs = gpu.BaseSet(0, 1, pts)
     ms = bs.msm(s)
     assert np.array_equal(gpu.point_to_affine(0, 1, ms), gpu.point_to_affine(0, 1, gpu.synth_expected_msm(0, 1, 42, s)))
+    plan = gpu.msm_last_plan()
+    assert plan["pair_levels"] == 3 and plan["irr_levels"] >= 1, plan     # the default path of the benchmark: regular + irregular levels
     mt = bs.msm(t)
     ds, dt = gpu.DeviceBuffer.from_numpy(s), gpu.DeviceBuffer.from_numpy(t)
     # s + t in Fr through the library's own subeq: s - (0 - t)
@@ -224,12 +226,15 @@ def test_g2_lane_split_repeatable_at_sizes_that_faulted_with_dpp(gpu):
 
 
 @pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("irr", [0, 1, 3])
 @pytest.mark.parametrize("levels", [1, 2, 3, 4])
-def test_g1_pairing_pass_small_with_special_cases(gpu, curve, levels, monkeypatch):
+def test_g1_pairing_pass_small_with_special_cases(gpu, curve, levels, irr, monkeypatch):
     """The batched-affine pairing pass (default only for >= 2^19 points) forced on a small G1 set that contains every side
     path: equal points in one bucket (affine doubling), opposite points (the pair cancels: the slot carries the generator and
     k_pair_fix takes it out of the bucket again), identity bases, zero / one scalars, an odd leftover per bucket -- with and
-    without the window table.  Result = oracle, bit-exact."""
+    without the window table, and with 0 / 1 / 3 irregular levels (no padding, ceil(g / 2) slots per bucket) behind the regular
+    ones: the twenty copies then double at the irregular levels too.  Result = oracle, bit-exact."""
+    monkeypatch.setenv("MNT753_MSM_IRR", str(irr))
     n = 260
     pts = gpu.synth_points(curve, 1, 31, n); sc = gpu.synth_scalars(curve, 32, n)
     pts[0] = 0; pts[n - 1] = 0
@@ -254,6 +259,7 @@ def test_g1_pairing_pass_many_cancellations(gpu, monkeypatch):
     """Every base appears together with its negative under the same scalar: every pair of the first level cancels, all
     buckets go through the fix-up kernel, and the sum is the identity."""
     monkeypatch.setenv("MNT753_MSM_PAIR", "3")
+    monkeypatch.setenv("MNT753_MSM_IRR", "2")
     n = 512
     half = gpu.synth_points(0, 1, 33, n // 2); sc_half = gpu.synth_scalars(0, 34, n // 2)
     pts = np.concatenate([half, half]); pts[n // 2:, 12:] = O.neg_fq(0, half[:, 12:])
@@ -264,11 +270,13 @@ def test_g1_pairing_pass_many_cancellations(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("irr", [0, 2])
 @pytest.mark.parametrize("levels", [1, 3])
-def test_g2_pairing_pass_small_with_special_cases(gpu, curve, levels, monkeypatch):
+def test_g2_pairing_pass_small_with_special_cases(gpu, curve, levels, irr, monkeypatch):
     """The pairing pass on the lane-split G2 kernels (default from ~2^17 points) forced on a small set with equal points
     (affine doubling over Fq2 / Fq3), identity bases, zero / one scalars and odd leftovers, with and without the window table;
     the extension-field inversion (norm shared across the 2 / 3 lanes of a point) is on this path.  Result = oracle."""
+    monkeypatch.setenv("MNT753_MSM_IRR", str(irr))
     n = 130
     pts = gpu.synth_points(curve, 2, 35, n); sc = gpu.synth_scalars(curve, 36, n)
     pts[0] = 0; pts[n - 1] = 0
@@ -282,11 +290,13 @@ def test_g2_pairing_pass_small_with_special_cases(gpu, curve, levels, monkeypatc
         assert np.array_equal(gpu_msm_affine(gpu, curve, 2, pts, sc), want)
 
 
+@pytest.mark.parametrize("irr", [0, 2])
 @pytest.mark.parametrize("curve,group", [(0, 2), (1, 2), (1, 1)])
-def test_pairing_pass_cancellations_every_group(gpu, curve, group, monkeypatch):
+def test_pairing_pass_cancellations_every_group(gpu, curve, group, irr, monkeypatch):
     """P and -P under the same scalar for every base: all first-level pairs cancel and go through k_pair_fix (generator in,
     generator out); checked on the groups not covered by test_g1_pairing_pass_many_cancellations."""
     monkeypatch.setenv("MNT753_MSM_PAIR", "2")
+    monkeypatch.setenv("MNT753_MSM_IRR", str(irr))
     n = 64
     half = gpu.synth_points(curve, group, 37, n // 2); sc_half = gpu.synth_scalars(curve, 38, n // 2)
     neg = np.stack([O.point_op(curve, group, 2, np.zeros_like(p), p) for p in half])   # O - P
@@ -296,13 +306,15 @@ def test_pairing_pass_cancellations_every_group(gpu, curve, group, monkeypatch):
     assert not got.any()
 
 
-@pytest.mark.parametrize("sort", ["part", "radix"])
+@pytest.mark.parametrize("sort,irr", [("part", None), ("radix", None), ("part", "3")])
 @pytest.mark.parametrize("group,logn", [(1, 19), (2, 17)])
-def test_skewed_scalars_with_the_pairing_pass(gpu, group, logn, sort, monkeypatch):
+def test_skewed_scalars_with_the_pairing_pass(gpu, group, logn, sort, irr, monkeypatch):
     """Both device-wide sort stages (the hand-written two-level counting sort, rocPRIM's radix sort).  The same three skewed scalar vectors at sizes where the pairing pass runs by default (G1 2^19, G2 2^17): a handful of
     giant buckets, thousands of empty ones between them (bisecting bucket walks), a sparse vector whose slot count is a
     fraction of the worst case (batch length derived on the device).  Exact through the discrete logs, and bounded."""
     monkeypatch.setenv("MNT753_MSM_SORT", sort)
+    if irr is not None:   # three irregular levels forced: one bucket of 2^19 * 40 entries goes through the source-word kernels as well
+        monkeypatch.setenv("MNT753_MSM_IRR", irr)
     n = 1 << logn
     pts = gpu.synth_points(0, group, 93, n)
     rnd = gpu.synth_scalars(0, 94, n)
@@ -326,6 +338,7 @@ def test_pairing_pass_thousands_of_cancellations_in_one_bucket(gpu, monkeypatch)
     """4096 copies of P and 4096 copies of -P under one scalar: every first-level pair of a handful of buckets cancels, so
     k_pair_fix has to take thousands of stand-ins out of single buckets (k * D by double-and-add, not k additions)."""
     monkeypatch.setenv("MNT753_MSM_PAIR", "3")
+    monkeypatch.setenv("MNT753_MSM_IRR", "3")   # ... and the pairs that survive the regular levels cancel at the irregular ones
     n = 8192
     base = gpu.synth_points(0, 1, 41, 2)
     s = gpu.synth_scalars(0, 42, 2)
@@ -340,7 +353,7 @@ def test_pairing_pass_thousands_of_cancellations_in_one_bucket(gpu, monkeypatch)
 
 @pytest.mark.parametrize("seed", range(12))
 def test_randomized_configurations_vs_oracle(gpu, seed, monkeypatch):
-    """Differential test over the knobs that select code paths: group, size, window table on / off, pairing levels 0-3, batch floor,
+    """Differential test over the knobs that select code paths: group, size, window table on / off, pairing levels 0-3, irregular levels 0-3, batch floor,
     sort stage, two-lane reduction / edge merge on / off, with the special values mixed into the scalars (0, 1, r - 1 as -1, repeated
     scalars) and the bases (identity, duplicates, a point and its negative under one scalar).  Every combination must give the
     oracle's (= libff's BDLO12) group element."""
@@ -350,7 +363,7 @@ def test_randomized_configurations_vs_oracle(gpu, seed, monkeypatch):
     env = {"MNT753_MSM_PRECOMP": str(int(rng.integers(0, 2))), "MNT753_MSM_PAIR": str(int(rng.integers(0, 4))),
            "MNT753_PAIR_MINB": str(int(rng.choice([1, 2, 8, 48]))), "MNT753_MSM_SORT": str(rng.choice(["atomic", "part", "radix"])),
            "MNT753_REDUCE_PAIR": str(int(rng.integers(0, 2))), "MNT753_EDGE_PAIR": str(int(rng.integers(0, 2))),
-           "MNT753_REDUCE_LINE": str(int(rng.integers(0, 2)))}
+           "MNT753_REDUCE_LINE": str(int(rng.integers(0, 2))), "MNT753_MSM_IRR": str(int(rng.integers(0, 4)))}
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     pts = gpu.synth_points(curve, group, 7000 + seed, n)

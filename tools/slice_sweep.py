@@ -59,7 +59,7 @@ def main():
                     best = dict(tm, wall_ms=wall)
                 ok = ok and bool(np.array_equal(pkg.point_to_affine(curve, group, out), exp))
             plan = pkg.msm_last_plan()
-            row = dict(curve=curve, group=group, log2_n=logn, forced_levels=lv, min_b=mb, levels=plan["pair_levels"], window_bits=plan["window_bits"],
+            row = dict(curve=curve, group=group, log2_n=logn, forced_levels=lv, min_b=mb, levels=plan["pair_levels"], irr_levels=plan.get("irr_levels", 0), window_bits=plan["window_bits"],
                        table=plan["window_table"], ok=ok, **{k: round(v, 3) for k, v in best.items()})
             rows.append(row)
             print(json.dumps(row), flush=True)

@@ -113,6 +113,7 @@ int mnt753_msm_set_point_cus(int) { return 256; }
 int mnt753_msm_last_timing(float o[5]) { for (int i = 0; i < 5; ++i) o[i] = 0; return 0; }
 int mnt753_msm_last_plan(int o[4]) { for (int i = 0; i < 4; ++i) o[i] = 0; return 0; }
 int mnt753_msm_last_pair_levels(void) { return 0; }
+int mnt753_msm_last_irr_levels(void) { return 0; }
 int mnt753_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, uint64_t* o) { if (bad_cg(curve, group)) return fail(MNT753_EINVAL, "point_add"); return CG(add_t, a, b, o); }
 int mnt753_point_scale(int curve, int group, const uint64_t* s, const uint64_t* p, uint64_t* o) { if (bad_cg(curve, group)) return fail(MNT753_EINVAL, "point_scale"); return CG(scale_t, s, p, o); }
 int mnt753_point_to_affine(int curve, int group, const uint64_t* p, uint64_t* o) { if (bad_cg(curve, group)) return fail(MNT753_EINVAL, "point_to_affine"); return CG(aff_t, p, o); }
