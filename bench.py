@@ -566,7 +566,7 @@ def main():
                     t = pkg.msm_last_timing()["total_ms"]
                     best = t if rep and (best is None or t < best) else (best if rep else None)
                 good = bool(np.array_equal(pkg.point_to_affine(curve, group, res), pkg.point_to_affine(curve, group, pkg.synth_expected_msm(curve, group, seed_p, sc_a))))
-                lv = pkg.msm_last_plan()["pair_levels"]
+                lv = pkg.msm_last_plan()["pair_levels"] + pkg.msm_last_plan().get("irr_levels", 0)
                 bs.close(); del d
                 return best, lv, good
             sweep, sweep_ok = {}, True
@@ -584,19 +584,32 @@ def main():
                     t, lv, good = msm_ms(1, group, seed_p, 43, arr[:k], s6[:k])
                     sweep[f"MNT6753_G{group}_2p{15 - shift}"] = {"ms": round(t, 3), "pair_levels": lv}
                     sweep_ok = sweep_ok and good
-            # predicted prove time on N devices: the G2 MSM and the four G1 MSMs of a slice back to back on its device (the point
-            # kernels own the whole chip: concurrency only fills launch gaps), compute_H on device 0 ahead of the H
-            # slices, the O(1) host tail; MNT6753 with its own compute_H share (2^15: 0.3 ms)
+            # the one MSM for C = Ht + Lt + r Bt1 over the concatenated set H | L | B1 (B::groth16_C): 3 x the points of a slice
+            for curve, name, base_n, seed_p in ((0, "MNT4753", n, 42), (1, "MNT6753", n6, 42)):
+                p3 = pkg.synth_points(curve, 1, seed_p, 3 * base_n)
+                s3 = pkg.synth_scalars(curve, 43, 3 * base_n)
+                for shift in (0, 1, 2, 3):
+                    k = (3 * base_n) >> shift
+                    t, lv, good = msm_ms(curve, 1, seed_p, 43, p3[:k], s3[:k])
+                    sweep[f"{name}_G1_3x2p{(args.log_n if curve == 0 else 15) - shift}"] = {"ms": round(t, 3), "pair_levels": lv}
+                    sweep_ok = sweep_ok and good
+                del p3, s3
+            # predicted prove time on N devices: the G2 MSM, A's MSM and the MSM for C of a slice back to back on its device (the point
+            # kernels own the whole chip: concurrency only fills launch gaps), compute_H on device 0 ahead of the
+            # slices of C, the O(1) host tail; MNT6753 with its own compute_H share (2^15: 0.3 ms)
             pred = {}
             for N, shift in ((1, 0), (2, 1), (4, 2), (8, 3)):
                 g1 = sweep[f"MNT4753_G1_2p{args.log_n - shift}"]["ms"]; gg2 = sweep[f"MNT4753_G2_2p{args.log_n - shift}"]["ms"]
-                pred[f"MNT4753_2p20_{N}gpu_s"] = round((gg2 + 4 * g1 + extras["compute_h_2p20_ms"] + 2.5) * 1e-3, 4)
+                gc = sweep[f"MNT4753_G1_3x2p{args.log_n - shift}"]["ms"]
+                pred[f"MNT4753_2p20_{N}gpu_s"] = round((gg2 + g1 + gc + extras["compute_h_2p20_ms"] + 2.5) * 1e-3, 4)
                 h1 = sweep[f"MNT6753_G1_2p{15 - shift}"]["ms"]; h2 = sweep[f"MNT6753_G2_2p{15 - shift}"]["ms"]
-                pred[f"MNT6753_2p15_{N}gpu_s"] = round((h2 + 4 * h1 + 0.3 + 2.5) * 1e-3, 4)
+                hc = sweep[f"MNT6753_G1_3x2p{15 - shift}"]["ms"]
+                pred[f"MNT6753_2p15_{N}gpu_s"] = round((h2 + h1 + hc + 0.3 + 2.5) * 1e-3, 4)
             extras["slice_sweep_ms"] = sweep
             extras["slice_sweep_parity_ok"] = sweep_ok
-            extras["predicted_prove_s"] = dict(pred, model="G2 + 4 x G1 MSM of one slice + compute_H (device 0) + 2.5 ms host tail and launch gaps; measured on ONE GPU at the "
-                                                     "slice sizes -- multi-GPU hardware was not available to the builder")
+            extras["predicted_prove_s"] = dict(pred, model="G2 MSM + G1 MSM (A) + G1 MSM over 3 x the points (C = Ht + Lt + r Bt1 over H | L | B1) of one slice + compute_H "
+                                                     "(device 0) + 2.5 ms host tail and launch gaps; measured on ONE GPU at the slice sizes -- multi-GPU hardware was "
+                                                     "not available to the builder")
             ok = ok and sweep_ok
             b2.close(); del g2
             line["extras"] = extras

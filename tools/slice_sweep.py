@@ -45,6 +45,8 @@ def main():
             variants += [(lv, mb) for lv in (0, 1, 2, 3, 4) for mb in ((8, 48) if lv else (None,))]
         for lv, mb in variants:
             for k, v in (("MNT753_MSM_PAIR", lv), ("MNT753_PAIR_MINB", mb)):
+                if args.quick:
+                    break            # --quick: whatever the environment says (tools/experiments/*.sh set the knobs themselves)
                 if v is None:
                     os.environ.pop(k, None)
                 else:
