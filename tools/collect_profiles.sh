@@ -29,6 +29,7 @@ python3 tools/synth_files.py MNT6753 15 $K/p6 $K/i6 > /dev/null
 M=$R/snark-challenge-prover-reference_amd/main_hip
 { echo "== main_hip MNT4753 d = 2^20 - 1, three proofs against resident parameters"; $M MNT4753 compute $K/p4 $K/i4 $K/o4 --repeat 3; sha256sum $K/o4;
   echo "== the reference's call order and its unfused compute_H (--ref-order --unfused-h)"; $M MNT4753 compute $K/p4 $K/i4 $K/o4r --ref-order --unfused-h | grep -i "total\|load"; sha256sum $K/o4r;
+  echo "== five separate MSMs (--unfused-c) instead of three"; $M MNT4753 compute $K/p4 $K/i4 $K/o4u --unfused-c --repeat 2 | grep -i "total\|load"; sha256sum $K/o4u;
   echo "== two logical devices sharing the one GPU of this box (MNT753_SHARE_DEVICE=1 --gpus 2)"; MNT753_SHARE_DEVICE=1 $M MNT4753 compute $K/p4 $K/i4 $K/o4s --gpus 2 --repeat 2 | grep -i "total\|load"; sha256sum $K/o4s;
   echo "== eight logical devices sharing the one GPU (MNT753_SHARE_DEVICE=1 --gpus 8): every code path of the 8-way split, none of its speed"; MNT753_SHARE_DEVICE=1 $M MNT4753 compute $K/p4 $K/i4 $K/o4e --gpus 8 --repeat 2 | grep -i "total\|load"; sha256sum $K/o4e;
   echo "== reference-minted hashes (tests/golden/oracle_hashes.json)"; grep output_sha256 tests/golden/oracle_hashes.json; } > $O/full_prove_MNT4753_2p20.log 2>&1
