@@ -14,7 +14,13 @@ HDRS := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.hip.h $(CSRC)/*.h include/*.h)
 HOST := $(PKG)/host
 MAIN := $(PKG)/main_hip
 
-all: $(LIB) $(MAIN) oracle
+LAZY_TEST := $(PKG)/lazy_c_test
+
+all: $(LIB) $(MAIN) $(LAZY_TEST) oracle
+
+# the wrapper's expression fusion from the caller's side (tools/host_tests/lazy_c_test.cpp; run by tests/test_prover_gpu.py)
+$(LAZY_TEST): tools/host_tests/lazy_c_test.cpp $(HOST)/prover_hip_functions.cpp include/prover_hip_functions.hpp include/mnt753_hip.h $(LIB)
+	g++ -O2 -std=c++17 -pthread -o $@ tools/host_tests/lazy_c_test.cpp $(HOST)/prover_hip_functions.cpp -L$(PKG) -lmnt753_hip -Wl,-rpath,'$$ORIGIN'
 
 $(MAIN): $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp include/prover_hip_functions.hpp include/mnt753_hip.h $(LIB)
 	g++ -O2 -std=c++17 -pthread -o $@ $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp -L$(PKG) -lmnt753_hip -Wl,-rpath,'$$ORIGIN'
@@ -42,7 +48,7 @@ $(BUILD)/san/main_hip_tsan: $(SAN_SRCS) include/prover_hip_functions.hpp include
 	g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -o $@ $(SAN_SRCS)
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(MAIN)
+	rm -rf $(BUILD) $(LIB) $(MAIN) $(LAZY_TEST)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean asan tsan

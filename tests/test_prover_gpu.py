@@ -100,6 +100,19 @@ def test_reference_driver_unchanged(gpu, curve, tmp_path):
 
 
 @pytest.mark.parametrize("curve", [0, 1])
+def test_expression_fusion_from_the_callers_side(gpu, curve):
+    """tools/host_tests/lazy_c_test.cpp over the wrapper: C = Ht + Lt + r Bt1 written in the reference's association and in two
+    others, and through B::groth16_C, runs as one MSM over H | L | B1 each time (four trace lines); seven other expressions over the
+    same unstarted multiexps (factor on the wrong term, partial sums, a value mixed in, a partial vector, a dropped value) are
+    evaluated the plain way; everything agrees with the three multiexps computed on their own."""
+    exe = os.path.join(O.ROOT, "snark-challenge-prover-reference_amd", "lazy_c_test")
+    params, inp, _ = G.e2e_paths(curve)
+    r = subprocess.run([exe, NAME[curve], params, inp], capture_output=True, text=True, env=dict(os.environ, MNT753_TRACE="1"), timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+    assert r.stderr.count("one MSM over H | L | B1") == 4, r.stderr
+
+
+@pytest.mark.parametrize("curve", [0, 1])
 def test_resident_parameters_batch_mode(gpu, curve, tmp_path):
     """main_hip proves several (input, output) pairs against parameters that stay resident on the GPU (window tables,
     workspaces, evaluation domain): the reference pays its 0.4-9 s parameter load per process (main.cpp:196-201)."""
