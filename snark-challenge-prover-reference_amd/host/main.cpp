@@ -21,8 +21,8 @@
 #include "../../include/prover_hip_functions.hpp"
 
 // Defaults = the fastest schedule on one MI355X: the G2 MSM is enqueued as soon as w is on the device, compute_H (one fused
-// call) follows as soon as ca / cb / cc are, then the four G1 MSMs.  The point kernels occupy every SIMD with long-lived
-// workgroups, so the ~60 short NTT kernels of compute_H must not be enqueued behind four MSMs (measured: 0.24 s with this
+// call) follows as soon as ca / cb / cc are, then the G1 MSMs.  The point kernels occupy every SIMD with long-lived
+// workgroups, so the ~60 short NTT kernels of compute_H must not be enqueued behind the G1 MSMs (measured: 0.24 s with this
 // order, 0.44-1.1 s with the reference's source order), and C = Ht + Lt + r Bt1 is one MSM over the concatenated base set
 // (B::groth16_C).  --ref-order keeps the call sequence of cuda_prover_piecewise.cu:64-90 (five multiexps, compute_H after the
 // first three, G1_scale, two G1_add -- the wrapper still runs the last three multiexps and that tail as one MSM, see LazyPoint in

@@ -321,7 +321,7 @@ public:
 
 // input file: w[m+1], ca[d+1], cb[d+1], cc[d+1], r   (generate_parameters.cpp:88-108, reader :48-76)
 // The constructor returns at once; a loader thread streams the four vectors to the device in file order and releases
-// them one by one, so kernels that only need w (four of the five MSMs) start while ca / cb / cc are still being read.
+// them one by one, so kernels that only need w (the G2 MSM and A's) start while ca / cb / cc are still being read.
 template <int CURVE>
 class mnt753_hip_impl<CURVE>::groth16_input {
 public:
