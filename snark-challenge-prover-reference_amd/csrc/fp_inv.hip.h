@@ -9,6 +9,14 @@
 //
 // Number of steps: the original divstep (delta starts at 1) needs at most floor((49 d + 57) / 17) steps for inputs below
 // 2^d (Bernstein-Yang 2019, Theorem 11.2); d = 754 gives 2176 <= 78 * 28 = 2184.
+// Measured and NOT adopted (round 3, -DMNT753_INV_EARLY_EXIT=1): the half-delta variant (delta starts at 1/2, as in libsecp256k1's
+// modinv) run UNTIL g = 0 IN EVERY LANE OF THE WAVE -- once g is 0 a batch is the identity (transition matrix 2^28 I), so lanes
+// that are done early are unharmed and correctness rests on no step bound.  Random 753-bit inputs need 1520 steps on average and
+// 1536 as the maximum over the 64 lanes of a wave (simulation over 2560 inputs: at most 1544): 55-56 batches instead of 78.  Same
+// registers, bit-identical results (131 GPU tests) -- and no gain: same box, alternating, G1 2^20 24.96 / 25.25 ms fixed against
+// 25.14 / 25.05 early, G2 2^20 65.98 / 65.79 against 69.36 / 69.76 (profiles/r03/ab_inversion_early_exit.txt).  The inversion is
+// the low-power phase of a pairing level (32-bit ALU work, no multiplies); shortening it shortens the time the chip spends below
+// its power limit, and the multiplier phases around it pay that back in clock.
 //
 // Representation inside the routine: 27 limbs of 28 bits, limbs 0..25 in [0, 2^28), limb 26 signed -- the same limb width
 // as fp753.hip.h, so a 28-step batch divides by exactly one limb.  d and e stay in (-2p, p), f and g in [-p, p].
@@ -17,9 +25,12 @@
 
 namespace mnt753 {
 
+#ifndef MNT753_INV_EARLY_EXIT
+#define MNT753_INV_EARLY_EXIT 0   // 1: half-delta divsteps until g = 0 in every lane of the wave (measured, see above)
+#endif
 struct InvMat { int32_t u, v, q, r; };
 
-// 28 division steps on the low limbs; returns the new eta = -delta and the transition matrix t with
+// 28 division steps on the low limbs; returns the new eta = -(delta + 1/2) (delta > 0 <=> eta < 0) and the transition matrix t with
 //   (f', g') = t (f, g) / 2^28
 HD int32_t inv_divsteps28(int32_t eta, uint32_t f0, uint32_t g0, InvMat& t) {
   uint32_t u = 1, v = 0, q = 0, r = 1;
@@ -33,7 +44,11 @@ HD int32_t inv_divsteps28(int32_t eta, uint32_t f0, uint32_t g0, InvMat& t) {
     const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;   // -f, -u, -v when delta > 0
     g += x & c2; q += y & c2; r += z & c2;
     c1 &= c2;                                     // swap case: delta > 0 and g odd
-    eta = (int32_t)(((uint32_t)eta ^ c1) - (c1 + 1u));   // delta <- 1 - delta (swap) or 1 + delta
+#if MNT753_INV_EARLY_EXIT
+    eta = (int32_t)(((uint32_t)eta ^ c1) - 1u);   // eta = -(delta + 1/2): delta <- 1 - delta (swap: eta <- -eta - 2) or 1 + delta (eta - 1)
+#else
+    eta = (int32_t)(((uint32_t)eta ^ c1) - (c1 + 1u));   // eta = -delta: delta <- 1 - delta (swap) or 1 + delta
+#endif
     f += g & c1; u += q & c1; v += r & c1;
     g >>= 1; u <<= 1; v <<= 1;
   }
@@ -93,7 +108,18 @@ HD void fp_inv_integer(uint32_t r[NL], const uint32_t a[NL]) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int it = 0; it < 78; ++it) {
+  for (int it = 0; it < (MNT753_INV_EARLY_EXIT ? 400 : 78); ++it) {   // (the cap of 400 is never reached: five times the proven worst case)
+#if MNT753_INV_EARLY_EXIT
+    // done when g = 0 in every lane that is still running with this one (g: inner limbs unsigned, top limb signed -- zero iff all are)
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) any |= (uint32_t)g[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!__any(any != 0)) break;
+#else
+    if (any == 0) break;
+#endif
+#endif
     InvMat t;
     eta = inv_divsteps28(eta, (uint32_t)f[0], (uint32_t)g[0], t);
     inv_update_de<M>(d, e, t);
