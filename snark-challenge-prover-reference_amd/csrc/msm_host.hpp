@@ -48,13 +48,15 @@ int pick_window_bits(size_t n) {
 }
 
 // window size when all windows share one bucket set: N*W bucket adds + one reduction of 2^(c-1) buckets.  A bucket of the reduction
-// costs `bucket_weight` additions of the accumulation: 4 for G1, 8 for the extension-field groups, whose reduction runs the general
-// addition against batched-affine accumulation (2^20 points, profiles/r03/window_width_sweep.txt: G1 25.45 / 25.53 / 26.74 ms at
-// c = 19 / 20 / 21, Fq2 G2 69.45 / 70.16 / 74.31 ms).
-int pick_precomp_bits(size_t n, double bucket_weight = 4.0) {
+// is priced at eight additions of the accumulation (with the irregular levels an addition got cheaper, the reduction did not), and
+// the base fields never go below c = 18: with fewer buckets than lanes a bucket's entries spread over several lanes and the edge
+// merge, one general addition per level, becomes the longest phase of a small MSM.  profiles/r03/window_width_sweep.txt, G1:
+//   2^20 points 25.0 / 24.3 / 25.0 / 26.2 ms at c = 18 / 19 / 20 / 21;  3 * 2^20: 66.0 / 64.1 / 62.3 / 62.0;  2^17: 5.3 ms at 18 against 6.2
+//   at 17;  MNT6753 2^15: 2.6 ms at 18 against 3.7 at 16.   Fq2 G2 2^20: 66.9 / 65.6 / 67.3 / 71.6 ms.
+int pick_precomp_bits(size_t n, double bucket_weight = 8.0, int min_c = 2) {
   if (const char* e = getenv("MNT753_MSM_PRE_C")) { int v = atoi(e); if (v >= 2 && v <= 24) return v; }
-  int best = 2; double best_cost = 1e300;
-  for (int c = 2; c <= 22; ++c) {
+  int best = min_c; double best_cost = 1e300;
+  for (int c = min_c; c <= 22; ++c) {
     double W = (754 + c - 1) / c;
     double cost = W * (double)n + bucket_weight * (double)(1u << (c - 1)) * 14.0 / 11.0;
     if (cost < best_cost) { best_cost = cost; best = c; }
@@ -224,7 +226,7 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   if (const char* e = getenv("MNT753_MSM_PRECOMP")) want_table = atoi(e) != 0 && n > 0;
   int pc = 0, pW = 1;
   if (want_table) {
-    pc = pick_precomp_bits(n, C::F::DEG == 1 ? 4.0 : 8.0);
+    pc = pick_precomp_bits(n, 8.0, C::F::DEG == 1 ? 18 : 2);
     pW = (754 + pc - 1) / pc;
     if ((uint64_t)pW * n >= 0x7fffffffull) { want_table = false; pc = 0; pW = 1; }   // row index must fit 31 bits
   }
