@@ -226,7 +226,12 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   if (const char* e = getenv("MNT753_MSM_PRECOMP")) want_table = atoi(e) != 0 && n > 0;
   int pc = 0, pW = 1;
   if (want_table) {
-    pc = pick_precomp_bits(n, 8.0, C::F::DEG == 1 ? 18 : 2);
+    // floors (and, for Fq3, the one width its sizes ever want) from the sweep: the bucket count at which one round of lanes holds
+    // the whole reduction -- 2^17 buckets for the base fields and the two-lane Fq2, 2^13 for the three-lane Fq3 (MNT6753 G2 2^15:
+    // 11.9 ms at c = 14 against 12.3-12.4 at 15 / 16; two-adicity 15 caps its size)
+    if (C::F::DEG == 1) pc = pick_precomp_bits(n, 8.0, 18);
+    else if (C::F::DEG == 2) pc = pick_precomp_bits(n, 8.0, n >= ((size_t)1 << 16) ? 18 : 2);
+    else pc = (n <= ((size_t)1 << 15) && !getenv("MNT753_MSM_PRE_C")) ? 14 : pick_precomp_bits(n, 8.0, 2);
     pW = (754 + pc - 1) / pc;
     if ((uint64_t)pW * n >= 0x7fffffffull) { want_table = false; pc = 0; pW = 1; }   // row index must fit 31 bits
   }
