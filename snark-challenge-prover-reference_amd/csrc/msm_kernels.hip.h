@@ -672,6 +672,9 @@ __device__ __forceinline__ void fp_store_blk(uint4* __restrict__ base, uint32_t 
 constexpr uint32_t PAIR_IMG_QUADS = 1792;                       // 2 points x 64 lanes x 14 quads (every field: NS * RQ * 2 <= 1792)
 constexpr uint32_t PAIR_LDS_WAVE_QUADS = PAIR_IMG_QUADS + 448 + 128;  // rows, prefix product, entries (4 x 128 u32)
 constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
+#ifndef MNT753_PAIR_DMA_STEPS_FIRST
+#define MNT753_PAIR_DMA_STEPS_FIRST 4
+#endif
 #ifndef MNT753_PAIR_DMA_STEPS_LATER
 #define MNT753_PAIR_DMA_STEPS_LATER 3
 #endif
@@ -1144,7 +1147,10 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       E opa, opb, res;
       // the image of the next slot is issued during the first DMA_STEPS products: gathered rows in five small portions (each
       // instruction holds the wave while the address path takes it), own planes in three (12.2 -> 11.1 ms and 5.36 -> 5.21 ms)
-      constexpr uint32_t DMA_STEPS = first ? 5u : MNT753_PAIR_DMA_STEPS_LATER;
+      // (first level, round 3: four portions for the base fields -- the last one then has two products to land in instead of one:
+      // G1 2^20 25.04 / 24.93 -> 24.54 / 24.12 ms, three portions 24.45 / 24.35; the lane-split Fq2 wants five: 66.9 / 67.3 ms against
+      // 68.5 / 68.5 with four; profiles/r03/ab_first_level_dma_portions.txt)
+      constexpr uint32_t DMA_STEPS = first ? (LN == 1 ? MNT753_PAIR_DMA_STEPS_FIRST : 5u) : MNT753_PAIR_DMA_STEPS_LATER;
       constexpr uint32_t PER_STEP = (BWD_PIECES + DMA_STEPS - 1u) / DMA_STEPS;
 #pragma nounroll
       for (int step = 0; step < 5; ++step) {
