@@ -25,9 +25,12 @@ $(LAZY_TEST): tools/host_tests/lazy_c_test.cpp $(HOST)/prover_hip_functions.cpp 
 $(MAIN): $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp include/prover_hip_functions.hpp include/mnt753_hip.h $(LIB)
 	g++ -O2 -std=c++17 -pthread -o $@ $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp -L$(PKG) -lmnt753_hip -Wl,-rpath,'$$ORIGIN'
 
-$(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
+# per-object dependency files (-MMD): a change to one header rebuilds the translation units that include it, not all of them
+# (the point-kernel units take minutes each)
+$(BUILD)/%.o: $(CSRC)/%.hip
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -MMD -MP -c $< -o $@
+-include $(HIP_OBJS:.o=.d)
 
 $(LIB): $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)

@@ -19,7 +19,11 @@ BASELINE.json's metric has two halves and the ONE JSON line rank 0 prints carrie
     (tests/golden/oracle_hashes.json, minted in the build container by tools/mint_oracle_hashes.py).  N = 1 only.
   * `prove_mnt6753` -- the same for configs[4]'s curve and size (MNT6753, d = 2^15 - 1), and `cpu_prove`: the reference's own
     `./main` (oracle/_ref/main, compiled from /root/reference by oracle/build_ref.sh) timed on this box's host cores on the same
-    files (MNT6753 2^15 always; MNT4753 at 2^17 by default and at 2^20 with BENCH_CPU_PROVE_FULL=1 -- minutes of CPU time).
+    files: MNT6753 2^15 and MNT4753 at the metric's own size, 2^20 (minutes of CPU time on the box's host threads;
+    BENCH_CPU_PROVE_FULL=0 falls back to the 2^17 files, BENCH_CPU_PROVE=0 skips the CPU provers).
+  * `exchange_us` -- the one exchange the sharded path has (multiexp.tcc:433-438: one projective point per rank, then the serial fold)
+    over RCCL: mean latency of 100 all_gathers of a G1 point through parallel.PointExchange (host -> device -> all_gather -> host).
+    N = 1: a world-size-1 RCCL communicator in a child process; N > 1: the communicator of the run itself.
 
 Secondary figures on the same line (N = 1): 2^20 FFT and compute_H (configs[2]), the G2 MSM at 2^20, the G1 MSM without
 the window table and the one-off cost of building the table, `roofline` for the dominant kernels and `cpu_baseline`.
@@ -44,7 +48,7 @@ LOG_N = 20
 ALGO_BYTES_PER_PAIR = 288          # 192 B affine G1 base + 96 B scalar, read once
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
 MODMUL_PEAK_PER_S = 22.0e9         # measured chip peak of the 753-bit Montgomery multiplier (profiles/r01/mulbench_mi355x.txt)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def sha256_file(path):
@@ -77,6 +81,65 @@ def respawn_under_torchrun(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+# ---- the exchange of the sharded path over RCCL -------------------------------------------------------------------------
+def time_exchange(pkg, device, reps=100):
+    """Mean / min latency in microseconds of `reps` all_gathers of one G1 projective point (36 u64) and of the block of three partial
+    points of a proof (A, B2 over Fq2, C: 36 + 72 + 36 u64) through parallel.PointExchange on the initialised process group."""
+    import numpy as np
+    out = {}
+    for name, words in (("g1_point", 36), ("proof_block", 144)):
+        ex = pkg.parallel.PointExchange(words, device)
+        local = np.arange(words, dtype=np.uint64) + 1
+        for _ in range(5):
+            got = ex.all_gather(local)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            got = ex.all_gather(local)
+            ts.append(time.perf_counter() - t0)
+        assert all(np.array_equal(g, local) for g in got), "exchange returned other words than were sent"
+        out[name] = {"words": words, "mean_us": 1e6 * sum(ts) / len(ts), "min_us": 1e6 * min(ts)}
+    return out
+
+
+def exchange_probe_main():
+    """Child process of the N = 1 run: a world-size-1 RCCL communicator on cuda:0 (backend "nccl" is RCCL on ROCm) and the
+    exchange through it.  Prints one JSON line."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import socket
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    t0 = time.perf_counter()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    res = time_exchange(pkg, device)
+    res["backend"] = dist.get_backend()
+    res["init_and_first_exchange_s"] = None
+    res["librccl_mapped"] = any("librccl" in l for l in open("/proc/self/maps"))
+    res["setup_s"] = time.perf_counter() - t0
+    dist.destroy_process_group()
+    print(json.dumps(res), flush=True)
+
+
+def exchange_leg():
+    """Run the probe above as a child before this process touches the GPU; a failure is reported, never fatal."""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-probe"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            return dict(json.loads(lines[-1]), world_size=1, note="world-size-1 RCCL communicator on one MI355X: the software path of the exchange "
+                        "(pinned host -> device -> all_gather_into_tensor -> host), no xGMI hop")
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    except Exception as ex:
+        return {"error": repr(ex)[:300]}
 
 
 # ---- PMC traffic of the dominant phase, measured in this run ---------------------------------------------------------
@@ -253,20 +316,22 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3):
 def prove_legs():
     """All the prove legs of the bench line, before this process touches the GPU."""
     legs = {}
-    legs["prove"], _ = prove_leg(20, "MNT4753")
     want_cpu = os.environ.get("BENCH_CPU_PROVE", "1") != "0"
+    # BASELINE.json's metric is the prove time on the FULL MNT4753 parameters "next to the CPU ./main baseline timed on the same box's
+    # host cores": the reference's own prover runs the same 2^20 files right after main_hip (libsnark/main.cpp:203-270; minutes of CPU
+    # time -- 401-551 s on the 8 cores of the build container, BASELINE.md section 2).  BENCH_CPU_PROVE_FULL=0 runs the 2^17 files instead.
+    full = want_cpu and os.environ.get("BENCH_CPU_PROVE_FULL", "1") != "0"
+    legs["prove"], cpu4 = prove_leg(20, "MNT4753", cpu=full)
     legs["prove_mnt6753"], cpu6 = prove_leg(15, "MNT6753", cpu=want_cpu)
     cpu = []
     if cpu6:
         cpu.append(cpu6)
-    if want_cpu:
-        # MNT4753: 2^20 takes minutes on any host (401-551 s on 8 cores, BASELINE.md section 2), so by default the CPU prover runs
-        # the 2^17 files (no minted hash at that size: its bytes are compared with main_hip's directly)
-        log2 = 20 if os.environ.get("BENCH_CPU_PROVE_FULL") == "1" else 17
-        gpu4, cpu4 = prove_leg(log2, "MNT4753", cpu=True, repeat=1)
+    if want_cpu and not full:
+        gpu4, cpu4 = prove_leg(17, "MNT4753", cpu=True, repeat=1)   # no minted hash at that size: its bytes are compared with main_hip's directly
         if cpu4:
             cpu4["gpu_parity_ok"] = gpu4.get("parity_ok")
-            cpu.append(cpu4)
+    if cpu4:
+        cpu.append(cpu4)
     legs["cpu_prove"] = cpu
     return legs
 
@@ -281,7 +346,11 @@ def main():
     ap.add_argument("--no-prove", action="store_true", help="skip the full-prove leg (N = 1 runs it by default)")
     ap.add_argument("--no-extras", action="store_true", help="skip the FFT / compute_H / G2 / table-less legs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure the HBM traffic of the dominant phase")
+    ap.add_argument("--no-exchange", action="store_true", help="skip the RCCL exchange-latency leg")
+    ap.add_argument("--exchange-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.exchange_probe:
+        return exchange_probe_main()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_under_torchrun(args))
@@ -296,6 +365,9 @@ def main():
     legs = None
     if world == 1 and not args.no_prove and args.log_n == LOG_N:
         legs = prove_legs()
+    exchange = None
+    if world == 1 and not args.no_exchange and args.log_n == LOG_N:
+        exchange = exchange_leg()
     traffic_live = None
     under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
     if world == 1 and not args.no_traffic and args.log_n == LOG_N and not under_profiler:   # (a profiled run has the GPU initialised already)
@@ -366,6 +438,12 @@ def main():
         return pkg.parallel.msm_sharded(pkg.api, 0, 1, local, comm_dev)
 
     out, elapsed, tot_ms = timed(step, args.steps, args.warmup)
+    if world > 1:
+        try:
+            exchange = dict(time_exchange(pkg, comm_dev), world_size=world, backend=dist.get_backend(),
+                            note="the run's own communicator: " + ("gloo on a shared GPU (development)" if share else "RCCL, one rank per GPU over xGMI"))
+        except Exception as ex:
+            exchange = {"error": repr(ex)[:300]}
     acc_ms = [t["accumulate_ms"] for t in tot_ms]
     plan = pkg.msm_last_plan()
     # parity of what was just timed: the whole array through its discrete logs (one host scalar multiplication)
@@ -448,6 +526,7 @@ def main():
                                    ", bit-exact vs libff::multi_exp",
                        "curve": "MNT4753", "group": "G1", "points": n, "points_per_gpu": n_local, "window_bits": plan_c, "windows": windows,
                        "window_table": plan["window_table"],
+                       "limbs": "27 x 28-bit limbs in u32 registers, 64-bit multiply-add columns (v_mad_u64_u32 / v_mad_i64_i32); exact integer arithmetic",
                        "parallelism": f"slice-per-gpu x{world}, all_gather (RCCL) of one projective point per rank, serial fold (multiexp.tcc:417-440)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_info": traffic_info, "kernel": kernel_name, "kernel_ms": acc,
@@ -464,6 +543,10 @@ def main():
         }
         if weak:
             line["weak"] = weak
+        if exchange is not None:
+            line["exchange"] = exchange
+            if "g1_point" in exchange:
+                line["exchange_us"] = exchange["g1_point"]["mean_us"]
 
     if world == 1:
         if not args.no_cpu_baseline:

@@ -170,6 +170,16 @@ int mnt753_vec_scale(int curve, uint64_t* dev_dst, const uint64_t* dev_src, cons
  * (coefficients_for_H, last entry 0). */
 int mnt753_compute_h(mnt753_domain* d, uint64_t* dev_ca, uint64_t* dev_cb, uint64_t* dev_cc, uint64_t* dev_h,
                      void* stream);
+/* The two halves of compute_H, for a prover that spreads it over the devices of a node (task parallelism, SURVEY.md section 8e: the
+ * transform is not sharded, but ca, cb and cc are independent until the pointwise step, cuda_prover_piecewise.cu:24-34):
+ *   _chain : x <- cosetFFT(iFFT(x)) in place on one vector of m elements (:24-27 for ca / cb, :33-34 for cc);
+ *   _finish: a <- icosetFFT((a * b - c) / Z), h <- a | 0 (:29-47); b and c are only read.
+ * A domain (its tables and work buffer) lives on the device that was current when it was created; both calls run there whatever the
+ * calling thread's current device is, and every vector handed to them must be on that device (mnt753_copy_peer_async brings the
+ * chained cb / cc from the devices that transformed them).  mnt753_compute_h == three _chain + one _finish on one device. */
+int mnt753_compute_h_chain(mnt753_domain* d, uint64_t* dev_vec, void* stream);
+int mnt753_compute_h_finish(mnt753_domain* d, uint64_t* dev_a, const uint64_t* dev_b, const uint64_t* dev_c, uint64_t* dev_h, void* stream);
+int mnt753_domain_device(const mnt753_domain* d);   /* logical device the domain lives on */
 
 /* ---- witness-map front end (the step before the hot path) -------------------------------------------
  * The reference evaluates the constraint system on the assignment on the CPU before the prover starts
@@ -205,6 +215,24 @@ int mnt753_synth_expected_msm(int curve, int group, uint64_t seed, size_t n, con
  * op: 0 a*b, 1 a+b, 2 a-b, 3 a^-1 (0 -> 0), 4 as_bigint(a), 5 -a, 6 a^2 (dedicated squaring), 7 wire->device->wire,
  * 8 a*b + a*a (fused two-product multiplier), 9 13*a (small-constant multiplier). */
 int mnt753_test_field_op(int mod, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* The coordinate field of G2 on the device, element-wise on n pairs of elements in wire form (c0 | c1 [| c2], host pointers):
+ * Fq2 = Fq[u]/(u^2 - 13) on MNT4753 (depends/libff/libff/algebra/fields/fp2.tcc:79-90 mul, :118-126 squared, :129-142 inverse,
+ * :58-70 + and -), Fq3 = Fq[u]/(u^3 - 11) on MNT6753 (fp3.tcc:83-96, :107-123, :126-143, :59-74).  split: 0 = the one-lane form
+ * (Karatsuba through one multiplier instance), 1 = the lane-split form the G2 point kernels run (two / three lanes per element,
+ * fused multi-product multipliers, ds_bpermute exchange).
+ * op: 0 a*b, 1 a*a, 2 a^-1, 3 a+b, 4 a-b, 5 -a, 6 (a == b) as the element 1 or 0 (the zero test the kernels branch on). */
+int mnt753_test_ext_op(int curve, int split, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* Every form of the group law the MSM kernels contain, on n pairs of points.  p_proj / q_proj / out_proj: projective X | Y | Z in
+ * wire form (any representative; Z == 0 is the identity), host pointers.  group: MNT753_G1 / MNT753_G2; split (G2 only): 0 = one
+ * lane per point, 1 = the lane-split configuration.  Reference: operator+ / mixed_add / dbl of mnt4753_G1 (depends/libff/libff/
+ * algebra/curves/mnt753/mnt4753/mnt4753_g1.cpp:134-207, :265-313, :315-346), mnt4753_G2 (mnt4753_g2.cpp:150-223, :281-329,
+ * :331-362), mnt6753_G1 (mnt6753_g1.cpp), mnt6753_G2 (mnt6753_g2.cpp:156-229, :287-335, :337-368).
+ * op: 0 P + Q through the point VM (bucket reduction, edge merge);  1 2P through the VM (window table; equal points);
+ *     2 P + Q with Q affine (Q's Z is taken as 1 unless 0) through the VM's mixed addition (bucket accumulation);
+ *     3 the same as straight-line code (bucket accumulation of the base fields and the two-lane Fq2; other fields: as op 2);
+ *     4 P + Q with two point-lanes per addition (narrow steps of the bucket reduction, edge merge of Fq3);
+ *     5 P + Q as straight-line code (wide steps of the bucket reduction, base fields; other fields: as op 0). */
+int mnt753_test_point_op(int curve, int group, int split, int op, const uint64_t* p_proj, const uint64_t* q_proj, size_t n, uint64_t* out_proj);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,13 @@
 //   fft_<curve>_<logm>.bin     v[m], FFT(v), iFFT(v), cosetFFT(v), icosetFFT(v)
 //   h_<curve>_<logm>.bin       ca[m], cb[m], cc[m], H[m+1]                (compute_H of libsnark/main.cpp:104-163)
 //   e2e_<curve>_{params,input}.bin   generate_parameters output at a small log2_d
+// Second capture (round 4, `mint_golden <dir> --kat`: writes ONLY these, the files above are never regenerated):
+//   extfield_<curve>.bin       N x [a, b, a*b, a^2, a^-1, a+b, a-b]       elements of Fqe = the coordinate field of G2
+//                              (Fq2 on MNT4753: fp2.tcc:79-142, Fq3 on MNT6753: fp3.tcc:83-143), write_fqe order c0 | c1 [| c2]
+//   groupkat_<curve>_g<k>.bin  N x [P, Q, P+Q, 2P, 2P+Q, 2P+3Q, P-Q]      operator+ / dbl / mixed_add of the reference's group
+//                              classes (mnt4753_g1.cpp:134-346, mnt4753_g2.cpp:150-362, mnt6753_g1.cpp, mnt6753_g2.cpp:156-368);
+//                              2P+Q is  P.dbl().mixed_add(Q)  (projective + affine),  2P+3Q is  P.dbl() + (Q.dbl() + Q)
+//   e2e_mnt6_2p10_{params,input}.bin   the reference generator's `fast` size for MNT6753 (generate_parameters.cpp:127-133)
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -174,13 +181,72 @@ void mint_h(const std::string& tag, size_t logm) {
   fclose(f);
 }
 
+static void only_c0(mnt4753_Fq2& a) { a.c1 = mnt4753_Fq::zero(); }
+static void only_c0(mnt6753_Fq3& a) { a.c1 = mnt6753_Fq::zero(); a.c2 = mnt6753_Fq::zero(); }
+template <typename ppT>
+void mint_extfield(const std::string& name) {
+  typedef Fqe<ppT> E;
+  FILE* f = open_out(name);
+  for (int i = 0; i < 24; ++i) {
+    E a = E::random_element(), b = E::random_element();
+    if (i == 0) a = E::one();
+    if (i == 1) b = E::zero();
+    if (i == 2) a = -E::one();
+    if (i == 3) b = a;
+    if (i == 4) { a = E::one() + E::one(); b = a.inverse(); }             // a * b = 1
+    if (i == 5) only_c0(a);                                              // only the constant coefficient is non-zero
+    if (i == 6) { a.c0 = Fq<ppT>::zero(); b.c0 = Fq<ppT>::zero(); }      // constant coefficients zero
+    if (i == 7) b = -a;
+    write_fqe<ppT>(f, a); write_fqe<ppT>(f, b); write_fqe<ppT>(f, a * b); write_fqe<ppT>(f, a.squared());
+    write_fqe<ppT>(f, a.inverse()); write_fqe<ppT>(f, a + b); write_fqe<ppT>(f, a - b);
+  }
+  fclose(f);
+}
+
+template <typename ppT, typename G>
+void mint_groupkat(const std::string& name) {
+  FILE* f = open_out(name);
+  for (int i = 0; i < 16; ++i) {
+    G P = Fr<ppT>::random_element() * G::one(), Q = Fr<ppT>::random_element() * G::one();
+    if (i == 1) Q = P;                    // operator+ : doubling branch
+    if (i == 2) Q = -P;                   // P + Q = O
+    if (i == 3) Q = G::zero();
+    if (i == 4) P = G::zero();
+    if (i == 5) Q = P.dbl();              // mixed_add meets an equal point: 2P + Q doubles
+    if (i == 6) Q = -(P.dbl());           // 2P + Q = O
+    if (i == 7) { P = G::zero(); Q = G::zero(); }
+    if (i == 8) Q = P + P + P;
+    P.to_affine_coordinates(); Q.to_affine_coordinates();
+    const G P2 = P.dbl();
+    G Q3 = Q.dbl() + Q;
+    write_g<ppT, G>(f, P); write_g<ppT, G>(f, Q);
+    write_g<ppT, G>(f, P + Q); write_g<ppT, G>(f, P2);
+    write_g<ppT, G>(f, Q.is_zero() ? P2 : P2.mixed_add(Q));   // (mixed_add reads other as affine: the identity has no affine form)
+    write_g<ppT, G>(f, P2 + Q3); write_g<ppT, G>(f, P - Q);
+  }
+  fclose(f);
+}
+
+static void mint_kat() {
+  mint_extfield<mnt4753_pp>("extfield_mnt4.bin");
+  mint_extfield<mnt6753_pp>("extfield_mnt6.bin");
+  mint_groupkat<mnt4753_pp, G1<mnt4753_pp>>("groupkat_mnt4_g1.bin");
+  mint_groupkat<mnt4753_pp, G2<mnt4753_pp>>("groupkat_mnt4_g2.bin");
+  mint_groupkat<mnt6753_pp, G1<mnt6753_pp>>("groupkat_mnt6_g1.bin");
+  mint_groupkat<mnt6753_pp, G2<mnt6753_pp>>("groupkat_mnt6_g2.bin");
+  // the reference generator's own `fast` size for MNT6753 (generate_parameters.cpp:127-133: log2_d = 10)
+  std::string p6 = g_dir + "/e2e_mnt6_2p10_params.bin", i6 = g_dir + "/e2e_mnt6_2p10_input.bin";
+  generate_paramaters<mnt6753_pp>(10, (char*)p6.c_str(), (char*)i6.c_str());
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: %s <output dir>\n", argv[0]); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: %s <output dir> [--kat]\n", argv[0]); return 2; }
   g_dir = argv[1];
   mnt4753_pp::init_public_params();
   mnt6753_pp::init_public_params();
   libff::inhibit_profiling_info = true;
   libff::inhibit_profiling_counters = true;
+  if (argc > 2 && std::string(argv[2]) == "--kat") { mint_kat(); return 0; }
 
   mint_field<mnt4753_pp>("A", "B");   // Fr(MNT4753) = modulus A, Fq(MNT4753) = modulus B
 

@@ -653,6 +653,26 @@ int oracle_field_op(int mod, int op, const uint64_t* a, const uint64_t* b, uint6
   memcpy(out, r.l, 96);
   return 0;
 }
+/* the coordinate field of G2 (Fq2 of MNT4753, Fq3 of MNT6753), elements c0 | c1 [| c2] in wire form: op 0 a*b (F/fp2.tcc:79-90,
+ * F/fp3.tcc:83-96), 1 a.squared() (F/fp2.tcc:118-126, F/fp3.tcc:107-123), 2 a.inverse() (F/fp2.tcc:129-142, F/fp3.tcc:126-143), 3 a+b, 4 a-b, 5 -a */
+int oracle_ext_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  if (curve < 0 || curve > 1) return -1;
+  group_t g; group_init(&g, curve, 2);
+  fe_t x, y, r;
+  fe_set_zero(&x); fe_set_zero(&y); fe_set_zero(&r);
+  for (int k = 0; k < g.f.deg; ++k) { memcpy(x.c[k].l, a + 12 * k, 96); if (b) memcpy(y.c[k].l, b + 12 * k, 96); }
+  switch (op) {
+    case 0: fe_mul(&r, &x, &y, &g.f); break;
+    case 1: fe_sqr(&r, &x, &g.f); break;
+    case 2: fe_inv(&r, &x, &g.f); break;
+    case 3: fe_add(&r, &x, &y, &g.f); break;
+    case 4: fe_sub(&r, &x, &y, &g.f); break;
+    case 5: fe_neg(&r, &x, &g.f); break;
+    default: return -1;
+  }
+  for (int k = 0; k < g.f.deg; ++k) memcpy(out + 12 * k, r.c[k].l, 96);
+  return 0;
+}
 /* op: 0 = P + Q, 1 = dbl(P), 2 = P - Q, 3 = scalar (Fr wire, in q) * P.   inputs / output affine wire */
 int oracle_point_op(int curve, int group, int op, const uint64_t* p, const uint64_t* q, uint64_t* out) {
   if (!valid_cg(curve, group)) return -1;

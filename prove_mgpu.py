@@ -13,15 +13,19 @@ Decomposition = the reference's own OpenMP chunking of an MSM (multiexp.tcc:402-
     three MSMs, a scalar multiplication and two additions -- B::groth16_C of the single-process wrapper), each with its window
     table; parameter loading is outside the timed window (libsnark/main.cpp:201-203).  --unfused-c keeps the five base sets and
     the reference's five multiexps;
-  * every rank streams the (small) input to its GPU (w first, the MSMs that only need w start behind it) and runs compute_H
-    itself -- the FFT is not sharded: 100 MB fit one GPU and a distributed NTT would move the whole vector over xGMI for ~3 % of
-    the work;
+  * nothing of the input is read twice and nothing is funnelled through rank 0 (round 4): rank g streams from the input file the range
+    of w that its slices multiply, and ranks 0 / 1 / 2 one vector of compute_H each -- ca / cb / cc (rank 0 takes cc too when there
+    are only two ranks).  Each of them runs x <- cosetFFT(iFFT(x)) on its own vector (mnt753_compute_h_chain); the transformed cb and
+    cc travel to rank 0 (RCCL send / recv over xGMI, 96 (d + 1) bytes each), which runs the pointwise step and the last transform
+    (mnt753_compute_h_finish) and scatters slice g of coefficients_for_H to rank g (send / recv, 96 d / N bytes each).  The FFT itself
+    is not sharded: 100 MB fit one GPU and a distributed NTT would move the whole vector over xGMI for ~3 % of the work;
   * the local MSMs run concurrently on their base sets' streams (mnt753_msm_start / _finish);
   * ONE all_gather per proof carries the three (five) partial points of every rank (36..108 u64 each -- latency bound);
     every rank folds them in rank order, rank 0 writes the proof.
 
-PyTorch is plumbing: torch.distributed (backend nccl = RCCL) and nothing else.  PROVE_SHARE_GPU=1 (development) lets all
-ranks share GPU 0 over gloo so the flow can be exercised on a single-GPU box.
+PyTorch is plumbing: torch.distributed (backend nccl = RCCL) and the device tensors its send / recv move.  PROVE_SHARE_GPU=1
+(development) lets all ranks share GPU 0 over gloo (the vectors then hop through host memory) so the flow can be exercised on a
+single-GPU box.
 """
 import json
 import os
@@ -91,36 +95,67 @@ def main():
 
     # ---- timed window: input load + compute + output write (main.cpp:203-270) ----
     # input file: w[m+1], ca[d+1], cb[d+1], cc[d+1], r   (generate_parameters.cpp:88-108).  Same data-driven order as
-    # host/main.cpp: w is streamed to the device first (mnt753_load_file_to_device), the MSMs that only need w are
-    # enqueued -- the G2 one first --, ca / cb / cc arrive while they run, then compute_H and the MSM that needs its result.
+    # host/main.cpp: this rank's range of w is streamed to the device first (mnt753_load_file_to_device), the MSMs that only need w are
+    # enqueued -- the G2 one first --, this rank's vector of compute_H arrives while they run.
     n_w, n_c = m + 1, d + 1
-    d_w = pkg.DeviceBuffer.from_file(input_path, 0, 96 * n_w)
-    d_h = pkg.DeviceBuffer(96 * (d + 2))
-    scal = {"A": (d_w, 0), "B1": (d_w, 0), "B2": (d_w, 0), "L": (d_w, 2), "H": (d_h, 0)}
-    # (A, B1, B2: w[i]; L: w[2 + i] = vector_Fr_offset(w, primary_input_size + 1); H: coefficients_for_H[i])
+    # the range of w this rank's slices multiply: A, B1, B2 take w[lo .. hi), L takes w[2 + lo .. 2 + hi)
+    w_first = min(spans["A"][0], spans["L"][0] + 2)
+    w_count = max(spans["A"][1], spans["L"][1] + 2) - w_first
+    d_w = pkg.DeviceBuffer.from_file(input_path, 96 * w_first, 96 * w_count)
+    w_at = lambda i: d_w.ptr.value + 96 * (i - w_first)        # device address of w[i]
+    lh, hh = spans["H"]
+    scal = {"A": (w_at, 0), "B1": (w_at, 0), "B2": (w_at, 0), "L": (w_at, 2)}
 
     def start(name):
-        buf, shift = scal[name]
+        at, shift = scal[name]
         lo, hi = spans[name]
-        sets[name].msm_start(buf.ptr.value + 96 * (lo + shift), hi - lo)
+        sets[name].msm_start(at(lo + shift), hi - lo)
 
     for name in ("B2", "A") if fused else ("B2", "A", "B1", "L"):
         start(name)
-    d_abc = [pkg.DeviceBuffer.from_file(input_path, 96 * n_w + k * 96 * n_c, 96 * n_c) for k in range(3)]
     r = np.fromfile(input_path, dtype=np.uint64, count=12, offset=96 * n_w + 3 * 96 * n_c)
-    t_in = time.perf_counter()
-    dom.compute_h(d_abc[0].ptr.value, d_abc[1].ptr.value, d_abc[2].ptr.value, d_h.ptr.value)
+    # compute_H: who holds which vector (parallel.h_vector_home)
+    home = pkg.parallel.h_vector_home(world)
+    mine = [k for k in ("ca", "cb", "cc") if home[k] == rank]
+    if world == 1:
+        bufs = {k: pkg.DeviceBuffer.from_file(input_path, 96 * n_w + i * 96 * n_c, 96 * n_c) for i, k in enumerate(("ca", "cb", "cc"))}
+        d_h = pkg.DeviceBuffer(96 * (d + 2))
+        t_in = time.perf_counter()
+        dom.compute_h(bufs["ca"].ptr.value, bufs["cb"].ptr.value, bufs["cc"].ptr.value, d_h.ptr.value)
+        h_at = lambda i: d_h.ptr.value + 96 * i
+    else:
+        import torch
+        tdev = torch.device("cuda", dev_index)
+        vec = {k: torch.empty(12 * n_c, dtype=torch.int64, device=tdev) for k in (("ca", "cb", "cc") if rank == 0 else mine)}
+        for i, k in enumerate(("ca", "cb", "cc")):
+            if k in mine:
+                pkg.api._check(pkg.lib().mnt753_load_file_to_device(input_path.encode(), 96 * n_w + i * 96 * n_c, 96 * n_c, vec[k].data_ptr()), "mnt753_load_file_to_device")
+        t_in = time.perf_counter()
+        for k in mine:
+            dom.compute_h_chain(vec[k].data_ptr())
+        pkg.lib().mnt753_sync(None)          # the chains ran on the library's default stream; the exchange uses torch.distributed's
+        pkg.parallel.gather_chained_to_rank0(dist, rank, world, vec, via_host=share)
+        h_mine = torch.empty(12 * max(hh - lh, 1), dtype=torch.int64, device=tdev)
+        t_h = None
+        if rank == 0:
+            t_h = torch.empty(12 * (d + 2), dtype=torch.int64, device=tdev)
+            torch.cuda.synchronize(tdev)
+            dom.compute_h_finish(vec["ca"].data_ptr(), vec["cb"].data_ptr(), vec["cc"].data_ptr(), t_h.data_ptr())
+            pkg.lib().mnt753_sync(None)
+        pkg.parallel.scatter_h_slices(dist, rank, world, d, t_h, h_mine, via_host=share)
+        torch.cuda.synchronize(tdev)
+        h_at = lambda i: h_mine.data_ptr() + 96 * (i - lh)
     if fused:
         # scalars of this rank's slice of the concatenated sum: h[lo_H, hi_H) | w[2 + lo_L, 2 + hi_L) | r * w[lo_B1, hi_B1)
-        (lh, hh), (ll, hl), (lb, hb) = spans["H"], spans["L"], spans["B1"]
+        (ll, hl), (lb, hb) = spans["L"], spans["B1"]
         n_c_set = (hh - lh) + (hl - ll) + (hb - lb)
         d_sc = pkg.DeviceBuffer(96 * max(n_c_set, 1))
-        pkg.copy_d2d(d_sc.ptr.value, d_h.ptr.value + 96 * lh, 96 * (hh - lh))
-        pkg.copy_d2d(d_sc.ptr.value + 96 * (hh - lh), d_w.ptr.value + 96 * (ll + 2), 96 * (hl - ll))
-        pkg.vec_scale(curve, d_sc.ptr.value + 96 * ((hh - lh) + (hl - ll)), d_w.ptr.value + 96 * lb, r, hb - lb)
+        pkg.copy_d2d(d_sc.ptr.value, h_at(lh), 96 * (hh - lh))
+        pkg.copy_d2d(d_sc.ptr.value + 96 * (hh - lh), w_at(ll + 2), 96 * (hl - ll))
+        pkg.vec_scale(curve, d_sc.ptr.value + 96 * ((hh - lh) + (hl - ll)), w_at(lb), r, hb - lb)
         sets["C"].msm_start(d_sc.ptr.value, n_c_set)
     else:
-        start("H")
+        sets["H"].msm_start(h_at(lh), hh - lh)
     partial = {name: sets[name].msm_finish() for name, _ in results}
     t_msm = time.perf_counter()
 

@@ -77,10 +77,15 @@ def lib():
         "mnt753_vec_subeq": (i, [i, vp, vp, sz, vp]),
         "mnt753_vec_scale": (i, [i, vp, vp, vp, sz, vp]),
         "mnt753_compute_h": (i, [vp, vp, vp, vp, vp, vp]),
+        "mnt753_compute_h_chain": (i, [vp, vp, vp]),
+        "mnt753_compute_h_finish": (i, [vp, vp, vp, vp, vp, vp]),
+        "mnt753_domain_device": (i, [vp]),
         "mnt753_synth_points": (i, [i, i, C.c_uint64, sz, u64p, i]),
         "mnt753_synth_scalars": (i, [i, C.c_uint64, sz, u64p]),
         "mnt753_synth_expected_msm": (i, [i, i, C.c_uint64, sz, u64p, u64p]),
         "mnt753_test_field_op": (i, [i, i, u64p, u64p, sz, u64p]),
+        "mnt753_test_ext_op": (i, [i, i, i, u64p, u64p, sz, u64p]),
+        "mnt753_test_point_op": (i, [i, i, i, i, u64p, u64p, sz, u64p]),
         "mnt753_r1cs_create": (i, [i, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "mnt753_r1cs_free": (i, [vp]),
         "mnt753_r1cs_domain_size": (sz, [vp]),
@@ -272,6 +277,17 @@ class Domain:
         _check(lib().mnt753_compute_h(self._h, C.c_void_p(int(ca)), C.c_void_p(int(cb)), C.c_void_p(int(cc)),
                                       C.c_void_p(int(h)), st), "mnt753_compute_h")
 
+    def compute_h_chain(self, vec, stream=None):
+        """vec <- cosetFFT(iFFT(vec)): the per-vector half of compute_H (runs on the domain's device)."""
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+        _check(lib().mnt753_compute_h_chain(self._h, C.c_void_p(int(vec)), st), "mnt753_compute_h_chain")
+
+    def compute_h_finish(self, a, b, c, h, stream=None):
+        """a <- icosetFFT((a * b - c) / Z), h <- a | 0: the joining half of compute_H."""
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p()
+        _check(lib().mnt753_compute_h_finish(self._h, C.c_void_p(int(a)), C.c_void_p(int(b)), C.c_void_p(int(c)), C.c_void_p(int(h)), st),
+               "mnt753_compute_h_finish")
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             lib().mnt753_domain_free(self._h)
@@ -383,6 +399,30 @@ def test_field_op(mod, op, a, b=None):
     out = np.zeros_like(a)
     _check(lib().mnt753_test_field_op(mod, op, pa, pb, a.size // 12, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_field_op")
     return out
+
+
+def test_ext_op(curve, split, op, a, b=None):
+    """Test hook: Fq2 (MNT4753) / Fq3 (MNT6753) on the device, element-wise; split = the lane-split form of the G2 kernels."""
+    a, pa = _u64(a)
+    b, pb = _u64(a if b is None else b)
+    out = np.zeros_like(a)
+    words = 12 * (2 if curve == 0 else 3)
+    _check(lib().mnt753_test_ext_op(curve, int(split), op, pa, pb, a.size // words, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_ext_op")
+    return out
+
+
+def test_point_op(curve, group, split, op, p, q=None):
+    """Test hook: one form of the device group law on projective wire points (see include/mnt753_hip.h)."""
+    p, pp = _u64(p)
+    q, pq = _u64(p if q is None else q)
+    out = np.zeros_like(p)
+    _check(lib().mnt753_test_point_op(curve, group, int(split), op, pp, pq, p.size // projective_words(curve, group),
+                                      out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_point_op")
+    return out
+
+
+test_ext_op.__test__ = False
+test_point_op.__test__ = False
 
 
 def mont_one(curve):

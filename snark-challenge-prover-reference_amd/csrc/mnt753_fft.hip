@@ -14,6 +14,7 @@ using namespace mnt753::host;
 
 struct mnt753_domain {
   int curve = 0, frm = 0;
+  int device = 0, logical_device = 0;                  // physical HIP ordinal / logical device the tables live on (the creating thread's current device)
   size_t m = 0;
   int logm = 0;
   uint32_t *tw_fwd = nullptr, *tw_inv = nullptr;       // omega^i, omega^-i            (m/2 each)
@@ -130,16 +131,20 @@ int fft_t(mnt753_domain* d, int kind, uint32_t* vec, hipStream_t st) {
 // compute_H (cuda_prover_piecewise.cu:18-53), all on the device:
 //   x -> cosetFFT(iFFT(x)) for x in {a, b, c} = stages(inv), *(g^i/m), stages(fwd)
 //   a = (a*b - c)/Z ; a = icosetFFT(a) ; h = a | 0
+// x -> cosetFFT(iFFT(x)) = stages(inv), *(g^i/m), stages(fwd)
 template <int M>
-int compute_h_t(mnt753_domain* d, uint32_t* ca, uint32_t* cb, uint32_t* cc, uint32_t* h, hipStream_t st) {
+int h_chain_t(mnt753_domain* d, uint32_t* vec, hipStream_t st) {
   const size_t m = d->m;
   const unsigned gb = (unsigned)((m + 255) / 256);
-  uint32_t* vecs[3] = {ca, cb, cc};
-  for (int v = 0; v < 3; ++v) {
-    if (int rc = run_stages<M>(d, vecs[v], d->tw_inv, st)) return rc;
-    hipLaunchKernelGGL((k_vec_mul_table<M>), dim3(gb), dim3(256), 0, st, vecs[v], d->cos_fwd_s, m);
-    if (int rc = run_stages<M>(d, vecs[v], d->tw_fwd, st)) return rc;
-  }
+  if (int rc = run_stages<M>(d, vec, d->tw_inv, st)) return rc;
+  hipLaunchKernelGGL((k_vec_mul_table<M>), dim3(gb), dim3(256), 0, st, vec, d->cos_fwd_s, m);
+  return run_stages<M>(d, vec, d->tw_fwd, st);
+}
+// a = (a*b - c)/Z ; a = icosetFFT(a) ; h = a | 0
+template <int M>
+int h_finish_t(mnt753_domain* d, uint32_t* ca, const uint32_t* cb, const uint32_t* cc, uint32_t* h, hipStream_t st) {
+  const size_t m = d->m;
+  const unsigned gb = (unsigned)((m + 255) / 256);
   hipLaunchKernelGGL((k_h_pointwise<M>), dim3(gb), dim3(256), 0, st, ca, cb, cc, d->consts + 1 * FPS_WORDS, d->consts + 2 * FPS_WORDS, m);
   if (int rc = run_stages<M>(d, ca, d->tw_inv, st)) return rc;
   hipLaunchKernelGGL((k_vec_mul_table<M>), dim3(gb), dim3(256), 0, st, ca, d->cos_inv_s, m);
@@ -147,6 +152,13 @@ int compute_h_t(mnt753_domain* d, uint32_t* ca, uint32_t* cb, uint32_t* cc, uint
   hipLaunchKernelGGL(k_copy_h, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, h, ca, m);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+template <int M>
+int compute_h_t(mnt753_domain* d, uint32_t* ca, uint32_t* cb, uint32_t* cc, uint32_t* h, hipStream_t st) {
+  uint32_t* vecs[3] = {ca, cb, cc};
+  for (int v = 0; v < 3; ++v)
+    if (int rc = h_chain_t<M>(d, vecs[v], st)) return rc;
+  return h_finish_t<M>(d, ca, cb, cc, h, st);
 }
 
 }  // namespace
@@ -165,6 +177,8 @@ int mnt753_domain_create(int curve, size_t m, mnt753_domain** out) {
   mnt753_domain* d = new (std::nothrow) mnt753_domain();
   if (!d) return set_error(MNT753_ENOMEM, "domain_create: host allocation failed");
   d->curve = curve; d->frm = frm; d->m = m; d->logm = logm;
+  d->device = current_physical_device(); d->logical_device = mnt753_get_device();
+  OnDevice on(d->device);
   int rc = frm == MOD_A ? build_tables<MOD_A>(d) : build_tables<MOD_B>(d);
   if (rc) { mnt753_domain_free(d); return rc; }
   *out = d;
@@ -173,6 +187,7 @@ int mnt753_domain_create(int curve, size_t m, mnt753_domain** out) {
 
 int mnt753_domain_free(mnt753_domain* d) {
   if (!d) return 0;
+  OnDevice on(d->device);
   void* ptrs[] = {d->tw_fwd, d->tw_inv, d->cos_fwd, d->cos_fwd_s, d->cos_inv_s, d->consts, d->work, d->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (d->work_free) (void)hipEventDestroy(d->work_free);
@@ -181,6 +196,7 @@ int mnt753_domain_free(mnt753_domain* d) {
 }
 
 size_t mnt753_domain_size(const mnt753_domain* d) { return d ? d->m : 0; }
+int mnt753_domain_device(const mnt753_domain* d) { return d ? d->logical_device : -1; }
 
 // Every transform of a domain ping-pongs through the domain's one work buffer.  Callers on different streams are serialised on
 // the device: a transform first waits for the event the previous one recorded (host threads must still not call into the
@@ -200,6 +216,7 @@ int mnt753_fft(mnt753_domain* d, int kind, uint64_t* dev_vec, void* stream) {
   if (!d || !dev_vec) return set_error(MNT753_EINVAL, "fft: null argument");
   if (int rc = require_device()) return rc;
   uint32_t* v = reinterpret_cast<uint32_t*>(dev_vec);
+  OnDevice on(d->device);
   if (int rc = work_acquire(d, (hipStream_t)stream)) return rc;
   const int rc = d->frm == MOD_A ? fft_t<MOD_A>(d, kind, v, (hipStream_t)stream) : fft_t<MOD_B>(d, kind, v, (hipStream_t)stream);
   return work_release(d, (hipStream_t)stream, rc);
@@ -210,6 +227,7 @@ int mnt753_divide_by_z_on_coset(mnt753_domain* d, uint64_t* dev_vec, void* strea
   if (int rc = require_device()) return rc;
   const unsigned gb = (unsigned)((d->m + 255) / 256);
   uint32_t* v = reinterpret_cast<uint32_t*>(dev_vec);
+  OnDevice on(d->device);
   if (d->frm == MOD_A) hipLaunchKernelGGL((k_vec_mul_const<MOD_A>), dim3(gb), dim3(256), 0, (hipStream_t)stream, v, d->consts + 3 * FPS_WORDS, d->m);
   else hipLaunchKernelGGL((k_vec_mul_const<MOD_B>), dim3(gb), dim3(256), 0, (hipStream_t)stream, v, d->consts + 3 * FPS_WORDS, d->m);
   HIP_TRY(hipGetLastError());
@@ -262,8 +280,31 @@ int mnt753_compute_h(mnt753_domain* d, uint64_t* dev_ca, uint64_t* dev_cb, uint6
   if (int rc = require_device()) return rc;
   uint32_t *a = reinterpret_cast<uint32_t*>(dev_ca), *b = reinterpret_cast<uint32_t*>(dev_cb), *c = reinterpret_cast<uint32_t*>(dev_cc),
            *h = reinterpret_cast<uint32_t*>(dev_h);
+  OnDevice on(d->device);
   if (int rc = work_acquire(d, (hipStream_t)stream)) return rc;
   const int rc = d->frm == MOD_A ? compute_h_t<MOD_A>(d, a, b, c, h, (hipStream_t)stream) : compute_h_t<MOD_B>(d, a, b, c, h, (hipStream_t)stream);
+  return work_release(d, (hipStream_t)stream, rc);
+}
+
+int mnt753_compute_h_chain(mnt753_domain* d, uint64_t* dev_vec, void* stream) {
+  if (!d || !dev_vec) return set_error(MNT753_EINVAL, "compute_h_chain: null argument");
+  if (int rc = require_device()) return rc;
+  OnDevice on(d->device);
+  if (int rc = work_acquire(d, (hipStream_t)stream)) return rc;
+  uint32_t* v = reinterpret_cast<uint32_t*>(dev_vec);
+  const int rc = d->frm == MOD_A ? h_chain_t<MOD_A>(d, v, (hipStream_t)stream) : h_chain_t<MOD_B>(d, v, (hipStream_t)stream);
+  return work_release(d, (hipStream_t)stream, rc);
+}
+
+int mnt753_compute_h_finish(mnt753_domain* d, uint64_t* dev_a, const uint64_t* dev_b, const uint64_t* dev_c, uint64_t* dev_h, void* stream) {
+  if (!d || !dev_a || !dev_b || !dev_c || !dev_h) return set_error(MNT753_EINVAL, "compute_h_finish: null argument");
+  if (int rc = require_device()) return rc;
+  OnDevice on(d->device);
+  if (int rc = work_acquire(d, (hipStream_t)stream)) return rc;
+  uint32_t* a = reinterpret_cast<uint32_t*>(dev_a);
+  const uint32_t *b = reinterpret_cast<const uint32_t*>(dev_b), *c = reinterpret_cast<const uint32_t*>(dev_c);
+  uint32_t* h = reinterpret_cast<uint32_t*>(dev_h);
+  const int rc = d->frm == MOD_A ? h_finish_t<MOD_A>(d, a, b, c, h, (hipStream_t)stream) : h_finish_t<MOD_B>(d, a, b, c, h, (hipStream_t)stream);
   return work_release(d, (hipStream_t)stream, rc);
 }
 

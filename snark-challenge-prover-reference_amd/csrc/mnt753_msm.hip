@@ -20,18 +20,6 @@ namespace {
 // MSM streams run at the lowest priority the device offers: an MSM is hundreds of milliseconds of throughput work,
 // and short kernels on the default stream (the NTTs of compute_H, launched while MSMs are in flight) should be
 // scheduled ahead of its remaining workgroups.
-// every entry point that takes a base set runs on the set's device and puts the thread back on its own afterwards
-// (HIP's own notion of the thread's current device, not the library's bookkeeping: a host thread that never called
-// mnt753_set_device, or whose device PyTorch changed, still gets its kernels, events and allocations on the set's GPU)
-struct OnDevice {
-  int back = -1;
-  explicit OnDevice(int dev) {
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
-    if (cur != dev) { (void)hipSetDevice(dev); back = cur; }
-  }
-  ~OnDevice() { if (back >= 0) (void)hipSetDevice(back); }
-};
 hipError_t create_msm_stream(hipStream_t* s) {
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }

@@ -95,7 +95,11 @@ MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   const uint64_t machine = machine_lanes(lanes_per_point);
   uint64_t lanes_target = machine * rounds;
   uint64_t T = (entries + lanes_target - 1) / lanes_target;
-  if (T < 16) T = 16;
+  // floor of entries per lane: a lane's walk is sequential (one mixed addition after the other, ~50 us each), so a small MSM is as
+  // long as its T; below the floor fewer lanes run and fewer edge pieces are left to merge.  MNT753_MSM_TMIN overrides (development).
+  uint64_t t_min = 16;
+  if (const char* e = getenv("MNT753_MSM_TMIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) t_min = (uint64_t)v; }
+  if (T < t_min) T = t_min;
   p.T = (uint32_t)T;
   p.n_lanes = (uint32_t)((entries + T - 1) / T);
   if (p.n_lanes == 0) p.n_lanes = 1;

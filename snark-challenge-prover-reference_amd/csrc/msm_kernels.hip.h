@@ -427,6 +427,39 @@ constexpr uint32_t ACC_LDS_BYTES = 4u * 2u * ACC_IMG_QUADS * 16u;
 #ifndef MNT753_ACC_LINE
 #define MNT753_ACC_LINE 1     // base fields: straight-line mixed addition in k_bucket_accumulate instead of the VM's
 #endif
+// acc += Q (Q affine) in a straight line: the same eleven products as the VM's program 0..10 (mixed_add, mnt4753_g1.cpp:265-313),
+// without its switch machine.  pc == PC_MADD: add; anything else (PC_END): the lane keeps its value (it only took over Q) but runs the
+// same instructions.  Equal points fall back to the VM's doubling.  Base fields and the two-lane Fq2 (k_bucket_accumulate).
+// A macro, expanded in place in the kernel: the accumulate kernel's register allocation is fragile (finding 4) and the
+// same statements behind a function call boundary -- even a force-inlined one -- came out with other spills (k_bucket_accumulate<Mnt6G1>
+// 68 -> 168 B of scratch).  pt_madd_line() wraps the same text for the test hook (mnt753_test_point_op).
+#define MNT753_MADD_LINE(C_, F_, acc_, Q_, pc_)                                                                        \
+  do {                                                                                                                 \
+    using E = typename F_::E;                                                                                          \
+    E u, v, uu, vv, vvv, R, A, w, X3, Y3;                                                                              \
+    F_::mul(w, acc_.Z, Q_.X); F_::sub(v, w, acc_.X);                                                                   \
+    F_::mul(w, acc_.Z, Q_.Y); F_::sub(u, w, acc_.Y);                                                                   \
+    const bool add = pc_ == PC_MADD;                                                                                   \
+    const bool same = add && F_::is_zero(u) && F_::is_zero(v);                                                         \
+    if constexpr (has_sqr<F_>::value) { F_::sqr(uu, u); F_::sqr(vv, v); } else { F_::mul(uu, u, u); F_::mul(vv, v, v); } \
+    F_::mul(vvv, v, vv);                                                                                               \
+    F_::mul(R, vv, acc_.X);                                                                                            \
+    F_::mul(w, uu, acc_.Z);                                                                                            \
+    F_::sub(A, w, vvv); F_::sub(A, A, R); F_::sub(A, A, R);      /* A = uu Z1 - vvv - 2R */                            \
+    F_::mul(X3, v, A);                                                                                                 \
+    F_::sub(w, R, A);                                                                                                  \
+    F_::mul(w, u, w);                                                                                                  \
+    F_::mul(R, vvv, acc_.Y);                                                                                           \
+    F_::sub(Y3, w, R);                                                                                                 \
+    F_::mul(w, vvv, acc_.Z);                                                                                           \
+    if (add && !same) { acc_.X = X3; acc_.Y = Y3; acc_.Z = w; }                                                        \
+    if (same) pt_vm<C_, false>(acc_, Q_, PC_DBL);                                                                      \
+  } while (0)
+template <class C>
+__device__ __forceinline__ void pt_madd_line(Proj<C>& acc, const Proj<C>& Q, int pc) {
+  using F = typename C::F;
+  MNT753_MADD_LINE(C, F, acc, Q, pc);
+}
 template <class C, bool BLOCKED = false>
 __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ offsets, uint32_t n_buckets,
@@ -534,25 +567,7 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
     if constexpr (((F::LANES == 1 && F::DEG == 1) || (F::LANES > 1 && F::LANES <= MNT753_ACC_LINE_SPLIT)) && MNT753_ACC_LINE) {
       // base fields: the mixed addition in a straight line (the same eleven products as the VM's program 0..10, without its
       // switch machine); lanes that only took over Q keep their value, equal points fall back to the VM's doubling
-      using E = typename F::E;
-      E u, v, uu, vv, vvv, R, A, w, X3, Y3;
-      F::mul(w, acc.Z, Q.X); F::sub(v, w, acc.X);
-      F::mul(w, acc.Z, Q.Y); F::sub(u, w, acc.Y);
-      const bool add = pc == PC_MADD;
-      const bool same = add && F::is_zero(u) && F::is_zero(v);
-      if constexpr (has_sqr<F>::value) { F::sqr(uu, u); F::sqr(vv, v); } else { F::mul(uu, u, u); F::mul(vv, v, v); }
-      F::mul(vvv, v, vv);
-      F::mul(R, vv, acc.X);
-      F::mul(w, uu, acc.Z);
-      F::sub(A, w, vvv); F::sub(A, A, R); F::sub(A, A, R);      // A = uu Z1 - vvv - 2R
-      F::mul(X3, v, A);
-      F::sub(w, R, A);
-      F::mul(w, u, w);
-      F::mul(R, vvv, acc.Y);
-      F::sub(Y3, w, R);
-      F::mul(w, vvv, acc.Z);
-      if (add && !same) { acc.X = X3; acc.Y = Y3; acc.Z = w; }
-      if (same) pt_vm<C, false>(acc, Q, PC_DBL);
+      MNT753_MADD_LINE(C, F, acc, Q, pc);
     } else {
       pt_vm<C, false>(acc, Q, pc);
     }
@@ -1644,6 +1659,39 @@ __global__ void __launch_bounds__(256, 1) k_edge_level_sum_pair(const uint32_t* 
   proj_store<C>(tmp + (size_t)j * PW, out);
   flags[level] = 1;
 }
+// out = P + Q, one lane per addition without the VM: operator+ of the reference (mnt4753_g1.cpp:134-207: add-1998-cmo-2, 12 products
+// + 2 squarings) in a straight line; identities pass through, equal points fall back to the VM (whose addition turns into its doubling).
+// A macro for the same reason as MNT753_MADD_LINE (k_reduce_step_line<Mnt4G1>: 4 spilled registers in place, 88 behind a force-inlined
+// function); declares `out`.  pt_add_line() wraps the same text for the test hook.
+#define MNT753_ADD_LINE(C_, F_, out_, P_, Q_)                                                                          \
+  const bool zP = pt_is_zero(P_), zQ = pt_is_zero(Q_);                                                                 \
+  typename F_::E x1z2, y1z2, z1z2, u, v, uu, vv, vvv, R, Aq, w;                                                        \
+  F_::mul(x1z2, P_.X, Q_.Z);                                                                                           \
+  F_::mul(y1z2, P_.Y, Q_.Z);                                                                                           \
+  F_::mul(z1z2, P_.Z, Q_.Z);                                                                                           \
+  F_::mul(w, Q_.X, P_.Z); F_::sub(v, w, x1z2);                                                                         \
+  F_::mul(w, Q_.Y, P_.Z); F_::sub(u, w, y1z2);                                                                         \
+  const bool same = F_::is_zero(u) && F_::is_zero(v);                                                                  \
+  Proj<C_> out_;                                                                                                       \
+  if constexpr (has_sqr<F_>::value) { F_::sqr(uu, u); F_::sqr(vv, v); } else { F_::mul(uu, u, u); F_::mul(vv, v, v); } \
+  F_::mul(vvv, v, vv);                                                                                                 \
+  F_::mul(R, vv, x1z2);                                                                                                \
+  F_::mul(w, uu, z1z2);                                                                                                \
+  F_::sub(Aq, w, vvv); F_::sub(Aq, Aq, R); F_::sub(Aq, Aq, R);                                                         \
+  F_::mul(out_.X, v, Aq);                                                                                              \
+  F_::sub(w, R, Aq);                                                                                                   \
+  F_::mul(w, u, w);                                                                                                    \
+  F_::mul(R, vvv, y1z2);                                                                                               \
+  F_::sub(out_.Y, w, R);                                                                                               \
+  F_::mul(out_.Z, vvv, z1z2);                                                                                          \
+  if (zP || zQ) out_ = zQ ? P_ : Q_;                                                                                   \
+  else if (same) { out_ = P_; pt_vm<C_, true>(out_, Q_, PC_ADD); }
+template <class C>
+__device__ __forceinline__ void pt_add_line(Proj<C>& res, const Proj<C>& P, const Proj<C>& Q) {
+  using F = typename C::F;
+  MNT753_ADD_LINE(C, F, out, P, Q)
+  res = out;
+}
 // One lane per addition without the VM: the same formulas in a straight line (14 products), for the wide steps of a base field
 // (a round of the VM's addition takes ~90 us, its switch machine and operand routing included).
 template <class C>
@@ -1683,28 +1731,7 @@ __global__ void __launch_bounds__(256, 1) k_reduce_step_line(const uint32_t* __r
   Proj<C> P, Q;
   if (e0) pt_set_zero(P); else proj_load<C>(P, src + (size_t)i0 * PW);
   if (e1) pt_set_zero(Q); else proj_load<C>(Q, src + (size_t)i1 * PW);
-  const bool zP = pt_is_zero(P), zQ = pt_is_zero(Q);
-  E x1z2, y1z2, z1z2, u, v, uu, vv, vvv, R, Aq, w;
-  F::mul(x1z2, P.X, Q.Z);
-  F::mul(y1z2, P.Y, Q.Z);
-  F::mul(z1z2, P.Z, Q.Z);
-  F::mul(w, Q.X, P.Z); F::sub(v, w, x1z2);
-  F::mul(w, Q.Y, P.Z); F::sub(u, w, y1z2);
-  const bool same = F::is_zero(u) && F::is_zero(v);
-  Proj<C> out;
-  if constexpr (has_sqr<F>::value) { F::sqr(uu, u); F::sqr(vv, v); } else { F::mul(uu, u, u); F::mul(vv, v, v); }
-  F::mul(vvv, v, vv);
-  F::mul(R, vv, x1z2);
-  F::mul(w, uu, z1z2);
-  F::sub(Aq, w, vvv); F::sub(Aq, Aq, R); F::sub(Aq, Aq, R);
-  F::mul(out.X, v, Aq);
-  F::sub(w, R, Aq);
-  F::mul(w, u, w);
-  F::mul(R, vvv, y1z2);
-  F::sub(out.Y, w, R);
-  F::mul(out.Z, vvv, z1z2);
-  if (zP || zQ) out = zQ ? P : Q;
-  else if (same) { out = P; pt_vm<C, true>(out, Q, PC_ADD); }
+  MNT753_ADD_LINE(C, F, out, P, Q)
   proj_store<C>(dst, out);
 }
 // the k + 1 points the host combines, per bucket set: out[set][0] = T = A_k[0], out[set][1 + l] = G_l

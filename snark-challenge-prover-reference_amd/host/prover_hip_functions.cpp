@@ -73,6 +73,19 @@ struct DeviceBuffer {
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
 };
+// Work enqueued through the C ABI's plain vector entry points (copies, vec_muleq / subeq / scale) lands on the calling thread's current
+// logical device: this scope puts the thread on `dev` for a few calls and back afterwards.  A no-op with one device.
+struct DeviceScope {
+  int back = -1;
+  explicit DeviceScope(int dev) {
+    if (mnt753_device_count() < 2) return;
+    const int cur = mnt753_get_device();
+    if (cur != dev) { check(mnt753_set_device(dev), "mnt753_set_device"); back = cur; }
+  }
+  ~DeviceScope() { if (back >= 0) (void)mnt753_set_device(back); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
 // one-shot readiness latch: set by the input loader thread, awaited by the first consumer of a vector
 struct Ready {
   std::mutex mu;
@@ -117,10 +130,15 @@ struct ShardedBases {
   struct Part {
     std::shared_ptr<BaseSetHolder> set;
     size_t lo = 0, hi = 0;
-    std::shared_ptr<DeviceBuffer> scalars;   // staging for the scalar slice on devices other than 0 (grow-only)
+    std::shared_ptr<DeviceBuffer> scalars;   // staging for the scalar slice on devices other than the vector's home (grow-only)
+    // the concatenated set H | L | B1 over several devices: part g = H[sub[0]) | L[sub[1]) | B1[sub[2]) -- slice g of EACH of the three
+    // vectors (multiexp.tcc:417-431 applied to each of the reference's three multiexps), so that device g needs the same range of w for
+    // all of its base sets and its own slice of coefficients_for_H
+    size_t sub_lo[3] = {0, 0, 0}, sub_hi[3] = {0, 0, 0};
   };
   std::vector<Part> parts;
   size_t n = 0;
+  bool interleaved = false;   // parts carry sub-ranges (the concatenated set on more than one device)
 };
 // one MSM in flight on every slice of a sharded vector
 struct PendingMsm {
@@ -140,6 +158,7 @@ struct LazyPoint {
   int which = 0;                                  //      which of its vectors (1 B1, 2 L, 3 H),
   size_t length = 0;                              //      and the scalars (kept alive by `keep`)
   std::function<const uint64_t*()> scalars;
+  int home = 0;                                   //      logical device that pointer is valid on
   std::shared_ptr<std::vector<DevSlice>> slices;
   size_t offset = 0;
   std::shared_ptr<void> keep;
@@ -158,7 +177,8 @@ static void read_exact(FILE* f, void* dst, size_t bytes, const char* path) {
 
 using namespace mnt753_hip_detail;
 
-template <int CURVE> struct mnt753_hip_impl<CURVE>::evaluation_domain { std::shared_ptr<DomainHolder> data; };
+// an evaluation domain is its size; the tables live per device (cached_domain), `data` is device 0's
+template <int CURVE> struct mnt753_hip_impl<CURVE>::evaluation_domain { std::shared_ptr<DomainHolder> data; size_t m = 0; };
 template <int CURVE> struct mnt753_hip_impl<CURVE>::field { uint64_t data[12]; };
 // G1 / G2 returned by multiexp_* are lazy: the MSM is in flight on its base set's stream until the value is first used
 template <int CURVE> struct mnt753_hip_impl<CURVE>::G1 { uint64_t data[36]; std::shared_ptr<PendingMsm> pending; std::shared_ptr<LazyPoint> lazy; };
@@ -171,11 +191,13 @@ template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_Fr {
   // several devices: ranges of the same vector that other devices hold (index = logical device, element indices of the underlying
   // buffer); empty for vectors that only exist on device 0 (coefficients_for_H)
   std::shared_ptr<std::vector<DevSlice>> slices;
-  // device pointer; waits (once) until the loader thread has put the vector on the device
+  std::shared_ptr<void> keep;     // buffers that kernels enqueued for this vector still read (staged copies of operands from other devices)
+  // device pointer (on device()); waits (once) until the loader thread has put the vector there
   uint64_t* ptr() const {
     if (ready) ready->wait();
     return reinterpret_cast<uint64_t*>(data->ptr) + 12 * offset;
   }
+  int device() const { return data->device; }   // logical device the vector lives on (cb / cc of a sharded prover: devices 1 / 2)
 };
 // owner / which: set for B1 (1), L (2), H (3) of fused parameters, whose own base sets exist only once something needs them
 template <int CURVE> struct mnt753_hip_impl<CURVE>::vector_G1 { std::shared_ptr<ShardedBases> data; groth16_params* owner = nullptr; int which = 0; };
@@ -252,9 +274,35 @@ public:
       B2 = load(MNT753_G2, g2w, m + 1, (size_t)-1);
       L = load(MNT753_G1, g1w, m - 1, d);
       H = load(MNT753_G1, g1w, d, 0);
-      if (fused) HLB = make_set(MNT753_G1, g1w, d + 2 * m, cat.data());
+      if (fused) HLB = make_hlb_set(g1w, cat);
     } catch (...) { fclose(f); throw; }
     fclose(f);
+  }
+  // the concatenated set H[d] | L[m-1] | B1[m+1] (host copy in `cat`): one device holds it as it is; over several devices part g is
+  // slice g of H, of L and of B1 (ShardedBases::Part::sub_lo / sub_hi)
+  std::shared_ptr<ShardedBases> make_hlb_set(size_t g1w, const std::vector<uint64_t>& cat) {
+    const int n_dev = std::max(1, mnt753_device_count());
+    if (n_dev == 1) return make_set(MNT753_G1, g1w, d + 2 * m, cat.data());
+    auto sb = std::make_shared<ShardedBases>();
+    sb->n = d + 2 * m;
+    sb->interleaved = true;
+    struct BackToDevice0 { ~BackToDevice0() { (void)mnt753_set_device(0); } } back;
+    const size_t len[3] = {d, m - 1, m + 1}, at[3] = {0, d, d + m - 1};
+    std::vector<uint64_t> rows;
+    for (int g = 0; g < n_dev; ++g) {
+      ShardedBases::Part part;
+      rows.clear();
+      for (int k = 0; k < 3; ++k) {
+        slice_bounds(len[k], n_dev, g, &part.sub_lo[k], &part.sub_hi[k]);
+        rows.insert(rows.end(), cat.begin() + g1w * (at[k] + part.sub_lo[k]), cat.begin() + g1w * (at[k] + part.sub_hi[k]));
+      }
+      part.lo = 0; part.hi = rows.size() / g1w;
+      part.set = std::make_shared<BaseSetHolder>();
+      check(mnt753_set_device(g), "mnt753_set_device");
+      check(mnt753_bases_create(CURVE, MNT753_G1, rows.data(), 0, part.hi, &part.set->h), "mnt753_bases_create");
+      sb->parts.push_back(part);
+    }
+    return sb;
   }
   // B1, L, H as base sets of their own (the reference's call sequence asks for them): built now if the parameters were loaded fused
   void ensure_separate() {
@@ -320,129 +368,168 @@ public:
 };
 
 // input file: w[m+1], ca[d+1], cb[d+1], cc[d+1], r   (generate_parameters.cpp:88-108, reader :48-76)
-// The constructor returns at once; a loader thread streams the four vectors to the device in file order and releases
-// them one by one, so kernels that only need w (the G2 MSM and A's) start while ca / cb / cc are still being read.
+// The constructor returns at once; loader threads stream the vectors to the devices and release them one by one, so kernels that
+// only need w (the G2 MSM and A's) start while ca / cb / cc are still being read.
+//
+// One device: one loader, file order (w, ca, cb, cc).
+// Several devices (B::use_devices): NOTHING of the proof's critical path is funnelled through device 0 (round 4).  Every device g has
+// its own loader thread, pinned staging buffers and PCIe link and reads from the file
+//   * the range of w that its slices of A / B1 / B2 (w[i]) and L (w[2 + i]) multiply -- 96 (m + 1) / N bytes -- first;
+//   * then ONE of the three vectors of compute_H: ca on device 0, cb on device 1, cc on device 2 (device 0 again when there are only
+//     two).  Each device runs cosetFFT(iFFT(.)) on its own vector (B::compute_H_fused, or the B::domain_* calls of the reference's
+//     compute_H<B>, which run where their vector lives), the transformed cb / cc travel to device 0 over xGMI
+//     (mnt753_copy_peer_async) and the pointwise step and the last transform run there: 134 MB instead of 403 MB over device 0's
+//     link, and two of the three transform chains off device 0;
+//   * device 0, last and needed by nobody on the critical path, the rest of w (so that B::input_w still is a whole vector there).
 template <int CURVE>
 class mnt753_hip_impl<CURVE>::groth16_input {
 public:
   std::shared_ptr<DeviceBuffer> w, ca, cb, cc;
-  std::shared_ptr<Ready> w_ready, ca_ready, cb_ready, cc_ready, r_ready;
+  std::shared_ptr<Ready> w_ready, ca_ready, cb_ready, cc_ready;
   size_t n_w = 0, n_c = 0;
   uint64_t r[12];
-  std::thread loader;
-  std::shared_ptr<double> load_seconds = std::make_shared<double>(0.0);
-  // several devices: device g > 0 streams the part of w its slices of A / B1 / B2 (w[i]) and L (w[2 + i]) multiply, from the file,
-  // on its own staging buffers and PCIe link, while device 0 reads w, ca, cb, cc -- nothing is funnelled through device 0
+  // seconds until the last loader was done (max over the loader threads; written before a thread sets its last latch)
+  struct LoadClock { std::mutex mu; double secs = 0; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); };
+  std::shared_ptr<LoadClock> clock = std::make_shared<LoadClock>();
+  // ranges of w resident per device (index = logical device): device g > 0 a buffer of its own, device 0 a view into w that is
+  // released as soon as ITS range is there (the whole of w follows later)
   std::shared_ptr<std::vector<DevSlice>> w_slices;
-  std::vector<std::thread> slice_loaders;
-  void start_slice_loaders(const std::string& path, size_t m) {
+  std::vector<std::thread> loaders;
+  struct Job { void* dst; size_t off, bytes; std::shared_ptr<Ready> ready; };   // ready: released after this job (may be null)
+
+  static void run_jobs(const std::string& path, int device, std::vector<Job> jobs, std::shared_ptr<LoadClock> clk, std::function<std::string()> tail) {
+    std::string err;
+    if (mnt753_device_count() > 1 && mnt753_set_device(device) != 0) err = std::string("mnt753_set_device: ") + mnt753_last_error();
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      const Job& job = jobs[k];
+      if (err.empty() && job.bytes && mnt753_load_file_to_device(path.c_str(), job.off, job.bytes, job.dst) != 0)
+        err = std::string("mnt753_load_file_to_device (device ") + std::to_string(device) + "): " + mnt753_last_error();
+      if (k + 1 == jobs.size()) {
+        if (err.empty() && tail) err = tail();
+        std::lock_guard<std::mutex> l(clk->mu);
+        clk->secs = std::max(clk->secs, std::chrono::duration<double>(std::chrono::steady_clock::now() - clk->t0).count());
+      }
+      if (job.ready) job.ready->set(err);
+    }
+  }
+  // the range of w device g multiplies: A, B1, B2 take w[lo .. hi) of slice g of m + 1 elements, L takes w[2 + lo .. 2 + hi) of m - 1
+  static void w_range(size_t m, int n_dev, int g, size_t* first, size_t* count) {
+    size_t lo_a, hi_a, lo_l, hi_l;
+    slice_bounds(m + 1, n_dev, g, &lo_a, &hi_a);
+    slice_bounds(m - 1, n_dev, g, &lo_l, &hi_l);   // vector_Fr_offset(w, primary_input_size + 1)
+    *first = std::min(lo_a, lo_l + 2);
+    *count = std::max(hi_a, hi_l + 2) - *first;
+  }
+  void check_size(const char* path, unsigned long long expect, const char* what) {
+    struct stat st;
+    if (stat(path, &st) != 0 || (unsigned long long)st.st_size != expect)
+      throw std::runtime_error(std::string(what) + " file size does not match the parameters (expected " + std::to_string(expect) + " bytes): " + path);
+  }
+  void read_r(const char* path, size_t r_off) {
+    FILE* f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open input file ") + path);
+    if (fseeko(f, (off_t)r_off, SEEK_SET) != 0 || fread(r, 1, 96, f) != 96) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
+    fclose(f);
+  }
+  // buffers, latches and the per-device ranges of w; vec_home[k] = device of ca / cb / cc
+  void allocate(size_t m, const int vec_home[3]) {
     const int n_dev = std::max(1, mnt753_device_count());
+    w_ready = std::make_shared<Ready>(); ca_ready = std::make_shared<Ready>(); cb_ready = std::make_shared<Ready>();
+    cc_ready = std::make_shared<Ready>();
+    struct BackToDevice0 { int n; ~BackToDevice0() { if (n > 1) (void)mnt753_set_device(0); } } back{n_dev};   // also when an allocation throws
+    w = std::make_shared<DeviceBuffer>(96 * n_w);
+    std::shared_ptr<DeviceBuffer>* vecs[3] = {&ca, &cb, &cc};
+    for (int k = 0; k < 3; ++k) {
+      if (n_dev > 1) check(mnt753_set_device(vec_home[k]), "mnt753_set_device");
+      *vecs[k] = std::make_shared<DeviceBuffer>(96 * n_c);
+    }
     if (n_dev < 2) return;
     w_slices = std::make_shared<std::vector<DevSlice>>((size_t)n_dev);
-    struct BackToDevice0 { ~BackToDevice0() { (void)mnt753_set_device(0); } } back;   // also when an allocation throws
-    for (int g = 1; g < n_dev; ++g) {
-      size_t lo_a, hi_a, lo_l, hi_l;
-      slice_bounds(m + 1, n_dev, g, &lo_a, &hi_a);   // A, B1, B2: scalars w[lo .. hi)
-      slice_bounds(m - 1, n_dev, g, &lo_l, &hi_l);   // L: scalars w[2 + lo .. 2 + hi)  (vector_Fr_offset(w, primary_input_size + 1))
+    for (int g = 0; g < n_dev; ++g) {
       DevSlice& sl = (*w_slices)[(size_t)g];
-      sl.first = std::min(lo_a, lo_l + 2);
-      sl.count = std::max(hi_a, hi_l + 2) - sl.first;
+      w_range(m, n_dev, g, &sl.first, &sl.count);
       sl.ready = std::make_shared<Ready>();
+      if (g == 0) { sl.buf = w; continue; }   // device 0's range starts at w[0] (slice 0 of every vector): a view into w
       check(mnt753_set_device(g), "mnt753_set_device");
       sl.buf = std::make_shared<DeviceBuffer>(96 * sl.count);
     }
-    check(mnt753_set_device(0), "mnt753_set_device");
-    for (int g = 1; g < n_dev; ++g) {
-      DevSlice sl = (*w_slices)[(size_t)g];
-      slice_loaders.emplace_back([path, sl, g]() {
-        std::string err;
-        if (mnt753_set_device(g) != 0 || mnt753_load_file_to_device(path.c_str(), 96 * sl.first, 96 * sl.count, sl.buf->ptr) != 0)
-          err = std::string("mnt753_load_file_to_device (device ") + std::to_string(g) + "): " + mnt753_last_error();
-        sl.ready->set(err);
-      });
-    }
   }
   groth16_input(const char* path, size_t d, size_t m) {
-    FILE* f = fopen(path, "rb");
-    if (!f) throw std::runtime_error(std::string("cannot open input file ") + path);
     n_w = m + 1; n_c = d + 1;
     const size_t r_off = 96 * (n_w + 3 * n_c);
-    {
-      struct stat st;
-      if (stat(path, &st) != 0 || (unsigned long long)st.st_size != (unsigned long long)r_off + 96ull) {
-        fclose(f);
-        throw std::runtime_error(std::string("input file size does not match the parameters (expected ") + std::to_string(r_off + 96) + " bytes): " + path);
-      }
-    }
-    if (fseeko(f, (off_t)r_off, SEEK_SET) != 0 || fread(r, 1, 96, f) != 96) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
-    fclose(f);
-    w = std::make_shared<DeviceBuffer>(96 * n_w);
-    ca = std::make_shared<DeviceBuffer>(96 * n_c);
-    cb = std::make_shared<DeviceBuffer>(96 * n_c);
-    cc = std::make_shared<DeviceBuffer>(96 * n_c);
-    w_ready = std::make_shared<Ready>(); ca_ready = std::make_shared<Ready>(); cb_ready = std::make_shared<Ready>();
-    cc_ready = std::make_shared<Ready>();
+    check_size(path, (unsigned long long)r_off + 96ull, "input");
+    read_r(path, r_off);
+    const int n_dev = std::max(1, mnt753_device_count());
+    const int vec_home[3] = {0, n_dev > 1 ? 1 : 0, n_dev > 2 ? 2 : 0};
+    allocate(m, vec_home);
     const std::string p(path);
-    start_slice_loaders(p, m);
-    struct Part { void* dst; size_t off, bytes; std::shared_ptr<Ready> ready; };
-    std::vector<Part> parts = {{w->ptr, 0, 96 * n_w, w_ready}, {ca->ptr, 96 * n_w, 96 * n_c, ca_ready},
-                               {cb->ptr, 96 * (n_w + n_c), 96 * n_c, cb_ready}, {cc->ptr, 96 * (n_w + 2 * n_c), 96 * n_c, cc_ready}};
-    auto secs_out = load_seconds;
-    loader = std::thread([p, parts, secs_out]() {
-      const auto t0 = std::chrono::steady_clock::now();
-      std::string err;
-      for (size_t k = 0; k < parts.size(); ++k) {
-        const Part& part = parts[k];
-        if (err.empty() && mnt753_load_file_to_device(p.c_str(), part.off, part.bytes, part.dst) != 0)
-          err = std::string("mnt753_load_file_to_device: ") + mnt753_last_error();
-        if (k + 1 == parts.size()) *secs_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        part.ready->set(err);
+    const size_t off_ca = 96 * n_w, off_cb = 96 * (n_w + n_c), off_cc = 96 * (n_w + 2 * n_c);
+    std::vector<std::vector<Job>> jobs((size_t)n_dev);
+    if (n_dev == 1) {
+      jobs[0] = {{w->ptr, 0, 96 * n_w, w_ready}, {ca->ptr, off_ca, 96 * n_c, ca_ready}, {cb->ptr, off_cb, 96 * n_c, cb_ready}, {cc->ptr, off_cc, 96 * n_c, cc_ready}};
+    } else {
+      for (int g = 1; g < n_dev; ++g) {
+        const DevSlice& sl = (*w_slices)[(size_t)g];
+        jobs[(size_t)g].push_back({sl.buf->ptr, 96 * sl.first, 96 * sl.count, sl.ready});
       }
-    });
+      const DevSlice& s0 = (*w_slices)[0];
+      jobs[0].push_back({w->ptr, 0, 96 * s0.count, s0.ready});
+      jobs[0].push_back({ca->ptr, off_ca, 96 * n_c, ca_ready});
+      jobs[(size_t)vec_home[1]].push_back({cb->ptr, off_cb, 96 * n_c, cb_ready});
+      jobs[(size_t)vec_home[2]].push_back({cc->ptr, off_cc, 96 * n_c, cc_ready});
+      jobs[0].push_back({(char*)w->ptr + 96 * s0.count, 96 * s0.count, 96 * (n_w - s0.count), w_ready});   // the rest of w, last
+    }
+    for (int g = 0; g < n_dev; ++g)
+      if (!jobs[(size_t)g].empty()) loaders.emplace_back(run_jobs, p, g, jobs[(size_t)g], clock, std::function<std::string()>());
   }
-  // witness file: w[m+1], r.  ca / cb / cc are evaluated on the device from the constraint system as soon as w is there.
+  // witness file: w[m+1], r.  ca / cb / cc are evaluated on device 0 from the constraint system as soon as w is there.
   groth16_input(const char* path, size_t d, size_t m, std::shared_ptr<R1csHolder> cs) {
     n_w = m + 1; n_c = d + 1;
-    struct stat st;
-    if (stat(path, &st) != 0 || (unsigned long long)st.st_size != 96ull * (n_w + 1))
-      throw std::runtime_error(std::string("witness file size does not match the parameters (expected ") + std::to_string(96 * (n_w + 1)) + " bytes): " + path);
+    check_size(path, 96ull * (n_w + 1), "witness");
     if (mnt753_r1cs_domain_size(cs->h) > n_c) throw std::runtime_error("the constraint system does not fit the parameters' evaluation domain");
     // the evaluation kernel gathers w[col] for col <= cs.m and copies w[0 .. num_inputs]: both must stay inside the m + 1 elements of w
     if (mnt753_r1cs_num_variables(cs->h) != m || mnt753_r1cs_num_inputs(cs->h) > m)
       throw std::runtime_error("the constraint system has " + std::to_string(mnt753_r1cs_num_variables(cs->h)) + " variables and " +
                                std::to_string(mnt753_r1cs_num_inputs(cs->h)) + " inputs, the parameters are for m = " + std::to_string(m));
-    FILE* f = fopen(path, "rb");
-    if (!f) throw std::runtime_error(std::string("cannot open witness file ") + path);
-    if (fseeko(f, (off_t)(96 * n_w), SEEK_SET) != 0 || fread(r, 1, 96, f) != 96) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
-    fclose(f);
-    w = std::make_shared<DeviceBuffer>(96 * n_w);
-    ca = std::make_shared<DeviceBuffer>(96 * n_c);
-    cb = std::make_shared<DeviceBuffer>(96 * n_c);
-    cc = std::make_shared<DeviceBuffer>(96 * n_c);
-    w_ready = std::make_shared<Ready>(); ca_ready = std::make_shared<Ready>(); cb_ready = std::make_shared<Ready>();
-    cc_ready = std::make_shared<Ready>();
+    read_r(path, 96 * n_w);
+    const int n_dev = std::max(1, mnt753_device_count());
+    const int vec_home[3] = {0, 0, 0};
+    allocate(m, vec_home);
     const std::string p(path);
-    start_slice_loaders(p, m);
-    auto secs_out = load_seconds;
+    for (int g = 1; g < n_dev; ++g) {
+      const DevSlice& sl = (*w_slices)[(size_t)g];
+      loaders.emplace_back(run_jobs, p, g, std::vector<Job>{{sl.buf->ptr, 96 * sl.first, 96 * sl.count, sl.ready}}, clock, std::function<std::string()>());
+    }
     auto w_ = w, ca_ = ca, cb_ = cb, cc_ = cc;
-    auto wr = w_ready, ar = ca_ready, br = cb_ready, cr = cc_ready;
-    const size_t nw = n_w, ncc = n_c;
-    loader = std::thread([p, secs_out, w_, ca_, cb_, cc_, wr, ar, br, cr, nw, ncc, cs]() {
-      const auto t0 = std::chrono::steady_clock::now();
+    auto ar = ca_ready, br = cb_ready, cr = cc_ready;
+    auto s0 = w_slices ? (*w_slices)[0].ready : std::shared_ptr<Ready>();
+    const size_t ncc = n_c;
+    // after w: evaluate the constraint system (device 0), then release ca / cb / cc together
+    auto tail = [w_, ca_, cb_, cc_, ncc, cs]() -> std::string {
+      if (mnt753_r1cs_evaluate(cs->h, reinterpret_cast<const uint64_t*>(w_->ptr), reinterpret_cast<uint64_t*>(ca_->ptr), reinterpret_cast<uint64_t*>(cb_->ptr),
+                               reinterpret_cast<uint64_t*>(cc_->ptr), ncc, nullptr) != 0 || mnt753_sync(nullptr) != 0)
+        return std::string("mnt753_r1cs_evaluate: ") + mnt753_last_error();
+      return std::string();
+    };
+    auto wr = w_ready;
+    auto clk = clock;
+    const size_t nw = n_w;
+    loaders.emplace_back([p, w_, wr, s0, ar, br, cr, clk, tail, nw]() {
+      // w first and released at once (the MSMs over w start), then the evaluation
       std::string err;
       if (mnt753_load_file_to_device(p.c_str(), 0, 96 * nw, w_->ptr) != 0) err = std::string("mnt753_load_file_to_device: ") + mnt753_last_error();
       wr->set(err);
-      if (err.empty() && (mnt753_r1cs_evaluate(cs->h, reinterpret_cast<const uint64_t*>(w_->ptr), reinterpret_cast<uint64_t*>(ca_->ptr),
-                                               reinterpret_cast<uint64_t*>(cb_->ptr), reinterpret_cast<uint64_t*>(cc_->ptr), ncc, nullptr) != 0 ||
-                          mnt753_sync(nullptr) != 0))
-        err = std::string("mnt753_r1cs_evaluate: ") + mnt753_last_error();
-      *secs_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (s0) s0->set(err);
+      if (err.empty()) err = tail();
+      {
+        std::lock_guard<std::mutex> l(clk->mu);
+        clk->secs = std::max(clk->secs, std::chrono::duration<double>(std::chrono::steady_clock::now() - clk->t0).count());
+      }
       ar->set(err); br->set(err); cr->set(err);
     });
   }
   ~groth16_input() {
-    if (loader.joinable()) loader.join();
-    for (auto& t : slice_loaders) if (t.joinable()) t.join();
+    for (auto& t : loaders) if (t.joinable()) t.join();
   }
 };
 
@@ -504,19 +591,45 @@ template <int CURVE> void HIP_B::print_G2(G2* a) {
 // Domains (twiddle and coset tables, ~0.5 GB of HBM at 2^20) are cached per (curve, size): creating one allocates and
 // frees device memory, which synchronises the whole device and would stall behind MSMs already in flight.  read_params
 // creates the domain for d + 1 ahead of time -- it depends on the parameters only, like the MSM window tables.
-template <int CURVE> static std::shared_ptr<DomainHolder> cached_domain(size_t d) {
+template <int CURVE> static std::shared_ptr<DomainHolder> cached_domain(size_t d, int device = 0) {
   static std::mutex mu;
-  static std::map<size_t, std::shared_ptr<DomainHolder>> cache;
+  static std::map<std::pair<int, size_t>, std::shared_ptr<DomainHolder>> cache;
   std::lock_guard<std::mutex> l(mu);
-  auto it = cache.find(d);
+  auto it = cache.find({device, d});
   if (it != cache.end()) return it->second;
   auto h = std::make_shared<DomainHolder>();
-  check(mnt753_domain_create(CURVE, d, &h->h), "mnt753_domain_create");
-  cache[d] = h;
+  {
+    DeviceScope on(device);   // a domain lives on the device that is current when it is created
+    check(mnt753_domain_create(CURVE, d, &h->h), "mnt753_domain_create");
+  }
+  cache[{device, d}] = h;
   return h;
 }
 template <int CURVE> typename HIP_B::evaluation_domain* HIP_B::get_evaluation_domain(size_t d) {
-  return new evaluation_domain{cached_domain<CURVE>(d)};
+  return new evaluation_domain{cached_domain<CURVE>(d), d};
+}
+// the tables of `domain` on the device a vector lives on (device 0's are in the handle; the others are built on first use --
+// B::read_params builds the ones a sharded proof needs)
+template <int CURVE> static mnt753_domain* domain_on(typename HIP_B::evaluation_domain* domain, int device) {
+  return device == 0 ? domain->data->h : cached_domain<CURVE>(domain->m, device)->h;
+}
+// staged blocks stay alive as long as the vector whose pending kernels read them
+static void keep_alive(std::shared_ptr<void>& slot, std::vector<std::shared_ptr<DeviceBuffer>>& bufs) {
+  if (bufs.empty()) return;
+  struct Chain { std::shared_ptr<void> prev; std::vector<std::shared_ptr<DeviceBuffer>> bufs; };
+  auto c = std::make_shared<Chain>();
+  c->prev = slot; c->bufs.swap(bufs);
+  slot = c;
+}
+// `v` (n elements) where device `dev` can read it: the vector itself, or a staged copy brought over by an asynchronous peer copy
+// (ordered behind everything enqueued on the source device's default stream); the staging block is appended to `keep`
+template <class V> static const uint64_t* operand_on(V* v, int dev, size_t n, std::vector<std::shared_ptr<DeviceBuffer>>& keep) {
+  if (v->device() == dev) return v->ptr();
+  std::shared_ptr<DeviceBuffer> tmp;
+  { DeviceScope on(dev); tmp = std::make_shared<DeviceBuffer>(96 * n); }
+  check(mnt753_copy_peer_async(dev, tmp->ptr, v->device(), v->ptr(), 96 * n), "mnt753_copy_peer_async");
+  keep.push_back(tmp);
+  return reinterpret_cast<const uint64_t*>(tmp->ptr);
 }
 
 template <int CURVE> static std::shared_ptr<PendingMsm> try_fuse(const std::shared_ptr<LazyPoint>& root);   // below
@@ -557,14 +670,24 @@ template <int CURVE> typename HIP_B::G1* HIP_B::G1_scale(field* a, G1* b) {
   return r;
 }
 
+// Element-wise operations run where their FIRST operand lives (the vector they overwrite); an operand on another device is brought
+// over first (operand_on).  With one device this is the plain call.
 template <int CURVE> void HIP_B::vector_Fr_muleq(vector_Fr* a, vector_Fr* b, size_t size) {
-  check(mnt753_vec_muleq(CURVE, a->ptr(), b->ptr(), size, nullptr), "mnt753_vec_muleq");
+  std::vector<std::shared_ptr<DeviceBuffer>> keep;
+  const uint64_t* bp = operand_on(b, a->device(), size, keep);
+  DeviceScope on(a->device());
+  check(mnt753_vec_muleq(CURVE, a->ptr(), bp, size, nullptr), "mnt753_vec_muleq");
+  keep_alive(a->keep, keep);
 }
 template <int CURVE> void HIP_B::vector_Fr_subeq(vector_Fr* a, vector_Fr* b, size_t size) {
-  check(mnt753_vec_subeq(CURVE, a->ptr(), b->ptr(), size, nullptr), "mnt753_vec_subeq");
+  std::vector<std::shared_ptr<DeviceBuffer>> keep;
+  const uint64_t* bp = operand_on(b, a->device(), size, keep);
+  DeviceScope on(a->device());
+  check(mnt753_vec_subeq(CURVE, a->ptr(), bp, size, nullptr), "mnt753_vec_subeq");
+  keep_alive(a->keep, keep);
 }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_offset(vector_Fr* a, size_t offset) {
-  return new vector_Fr{a->data, a->size, offset, a->ready, a->slices};
+  return new vector_Fr{a->data, a->size, offset, a->ready, a->slices, a->keep};
 }
 template <int CURVE> void HIP_B::vector_Fr_copy_into(vector_Fr* src, vector_Fr* dst, size_t length) {
   // MNT4753: dst[i] = src[i] ignoring offsets (prover_reference_functions.cpp:209-212);
@@ -572,41 +695,67 @@ template <int CURVE> void HIP_B::vector_Fr_copy_into(vector_Fr* src, vector_Fr* 
   if (src->ready) src->ready->wait();
   if (dst->ready) dst->ready->wait();
   const uint64_t* s = reinterpret_cast<const uint64_t*>(src->data->ptr) + (CURVE == 1 ? 12 * src->offset : 0);
-  check(mnt753_copy_d2d(dst->data->ptr, s, 96 * length), "mnt753_copy_d2d");
+  if (src->device() == dst->device()) {
+    DeviceScope on(dst->device());
+    check(mnt753_copy_d2d(dst->data->ptr, s, 96 * length), "mnt753_copy_d2d");
+  } else {
+    check(mnt753_copy_peer_async(dst->device(), dst->data->ptr, src->device(), s, 96 * length), "mnt753_copy_peer_async");
+  }
 }
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::vector_Fr_zeros(size_t length) {
   auto b = std::make_shared<DeviceBuffer>(96 * length);
+  DeviceScope on(b->device);
   check(mnt753_dev_memset(b->ptr, 0, 96 * length), "mnt753_dev_memset");
-  return new vector_Fr{b, length, 0, nullptr, nullptr};
+  return new vector_Fr{b, length, 0, nullptr, nullptr, nullptr};
 }
 
+// the transforms run on the device their vector lives on, with that device's tables
 template <int CURVE> void HIP_B::domain_iFFT(evaluation_domain* domain, vector_Fr* a) {
-  check(mnt753_fft(domain->data->h, MNT753_IFFT, a->ptr(), nullptr), "mnt753_fft(iFFT)");
+  check(mnt753_fft(domain_on<CURVE>(domain, a->device()), MNT753_IFFT, a->ptr(), nullptr), "mnt753_fft(iFFT)");
 }
 template <int CURVE> void HIP_B::domain_cosetFFT(evaluation_domain* domain, vector_Fr* a) {
-  check(mnt753_fft(domain->data->h, MNT753_COSET_FFT, a->ptr(), nullptr), "mnt753_fft(cosetFFT)");
+  check(mnt753_fft(domain_on<CURVE>(domain, a->device()), MNT753_COSET_FFT, a->ptr(), nullptr), "mnt753_fft(cosetFFT)");
 }
 template <int CURVE> void HIP_B::domain_icosetFFT(evaluation_domain* domain, vector_Fr* a) {
-  check(mnt753_fft(domain->data->h, MNT753_ICOSET_FFT, a->ptr(), nullptr), "mnt753_fft(icosetFFT)");
+  check(mnt753_fft(domain_on<CURVE>(domain, a->device()), MNT753_ICOSET_FFT, a->ptr(), nullptr), "mnt753_fft(icosetFFT)");
 }
 template <int CURVE> void HIP_B::domain_divide_by_Z_on_coset(evaluation_domain* domain, vector_Fr* a) {
-  check(mnt753_divide_by_z_on_coset(domain->data->h, a->ptr(), nullptr), "mnt753_divide_by_z_on_coset");
+  check(mnt753_divide_by_z_on_coset(domain_on<CURVE>(domain, a->device()), a->ptr(), nullptr), "mnt753_divide_by_z_on_coset");
 }
 template <int CURVE> size_t HIP_B::domain_get_m(evaluation_domain* domain) { return mnt753_domain_size(domain->data->h); }
 
 // sum_{i < length} scalars[i] * bases[i] over the slices of a sharded vector: slice g covers [lo_g, hi_g) of the bases and runs on
-// device g, on that base set's own stream.  Where the scalars come from, per device:
-//   * device 0: the vector itself (dev0(), which waits for the input loader if the vector is still streaming in);
-//   * device g > 0, the vector has a resident range there (w: DevSlice, loaded from the file by device g's own loader): that;
+// device g, on that base set's own stream.  Where the scalars of a slice come from, in this order:
+//   * a range of the vector that is resident on device g (w: DevSlice, streamed from the file by device g's own loader -- device 0's
+//     range is released before the whole of w is there);
+//   * the vector itself when device g is its home (waits for the input loader if the vector is still streaming in);
 //   * otherwise (coefficients_for_H, computed on device 0): an asynchronous peer copy into a grow-only staging buffer on device g,
-//     ordered behind device 0's default stream (compute_H) by an event and ahead of the MSM by the destination's default stream --
-//     the host never blocks (mnt753_copy_peer_async).
+//     ordered behind the home device's default stream (compute_H) by an event and ahead of the MSM by the destination's default
+//     stream -- the host never blocks (mnt753_copy_peer_async).
 // The slices of the other devices are enqueued first: their inputs are ready first, and device 0 is the one that waits for the file.
 struct ScalarSource {
-  std::function<const uint64_t*()> dev0;       // element `offset` of the vector on device 0
-  const std::vector<DevSlice>* slices;         // ranges of the underlying buffer on the other devices, or null
+  std::function<const uint64_t*()> home_ptr;   // element `offset` of the vector on its home device
+  int home;                                    // logical device of that pointer
+  const std::vector<DevSlice>* slices;         // ranges of the underlying buffer resident per device (index = device), or null
   size_t offset;                               // element offset of the logical vector inside the underlying buffer
 };
+// elements [lo, hi) of the source where device g can read them without a copy, or null
+static const uint64_t* resident_on(const ScalarSource& src, int g, size_t lo, size_t hi) {
+  const DevSlice* sl = src.slices && (size_t)g < src.slices->size() && (*src.slices)[(size_t)g].buf ? &(*src.slices)[(size_t)g] : nullptr;
+  if (sl && src.offset + lo >= sl->first && src.offset + hi <= sl->first + sl->count) {
+    sl->ready->wait();
+    return reinterpret_cast<const uint64_t*>(sl->buf->ptr) + 12 * (src.offset + lo - sl->first);
+  }
+  if (g == src.home) return src.home_ptr() + 12 * lo;
+  return nullptr;
+}
+// elements [lo, hi) of the source into `dst` on device g (the calling thread's current device): a local copy on g's default stream,
+// or a peer copy ordered behind the home device's default stream
+static void fetch_into(const ScalarSource& src, int g, size_t lo, size_t hi, uint64_t* dst) {
+  if (hi <= lo) return;
+  if (const uint64_t* p = resident_on(src, g, lo, hi)) check(mnt753_copy_d2d(dst, p, 96 * (hi - lo)), "mnt753_copy_d2d");
+  else check(mnt753_copy_peer_async(g, dst, src.home, src.home_ptr() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
+}
 static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarSource& src, size_t length, const char* what) {
   auto pend = std::make_shared<PendingMsm>();
   const int n_dev = (int)sb.parts.size();
@@ -616,23 +765,12 @@ static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarS
     ShardedBases::Part& part = sb.parts[(size_t)g];
     const size_t lo = part.lo, hi = std::min(part.hi, length);
     if (hi <= lo) continue;
-    const uint64_t* sc;
-    if (g == 0) {
-      sc = src.dev0() + 12 * lo;
-    } else {
-      const DevSlice* sl = src.slices && (size_t)g < src.slices->size() && (*src.slices)[(size_t)g].buf ? &(*src.slices)[(size_t)g] : nullptr;
-      if (sl && src.offset + lo >= sl->first && src.offset + hi <= sl->first + sl->count) {
-        sl->ready->wait();
-        sc = reinterpret_cast<const uint64_t*>(sl->buf->ptr) + 12 * (src.offset + lo - sl->first);
-      } else {
-        if (!part.scalars || part.scalars->bytes < 96 * (hi - lo)) {
-          struct BackToDevice0 { ~BackToDevice0() { (void)mnt753_set_device(0); } } back;   // also when the allocation throws
-          check(mnt753_set_device(g), "mnt753_set_device");
-          part.scalars = std::make_shared<DeviceBuffer>(96 * (part.hi - part.lo));
-        }
-        check(mnt753_copy_peer_async(g, part.scalars->ptr, 0, src.dev0() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
-        sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
-      }
+    const uint64_t* sc = resident_on(src, g, lo, hi);
+    if (!sc) {
+      DeviceScope on(g);
+      if (!part.scalars || part.scalars->bytes < 96 * (hi - lo)) part.scalars = std::make_shared<DeviceBuffer>(96 * (part.hi - part.lo));
+      check(mnt753_copy_peer_async(g, part.scalars->ptr, src.home, src.home_ptr() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
+      sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
     }
     check(mnt753_msm_start(part.set->h, 0, sc, 1, hi - lo, nullptr), what);
     pend->sets[(size_t)g] = part.set;
@@ -642,21 +780,59 @@ static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarS
   return pend;
 }
 template <class V> static ScalarSource source_of(V* v) {
-  return ScalarSource{[v]() { return v->ptr(); }, v->slices.get(), v->offset};
+  return ScalarSource{[v]() { return (const uint64_t*)v->ptr(); }, v->device(), v->slices.get(), v->offset};
 }
-// the scalars h | w_L | r w of the concatenated sum, assembled on device 0's default stream (two copies and one scaling pass, ~0.2 ms:
-// behind compute_H, ahead of the MSM), and the MSM over H | L | B1
+// C = Ht + Lt + r Bt1 as ONE multi-scalar multiplication per device over the concatenated base set.
+//   one device : the set is H | L | B1 and the scalars h | w_L | r w are assembled on the default stream (two copies and one scaling
+//                pass, ~0.2 ms: behind compute_H, ahead of the MSM);
+//   N devices  : part g of the set is H_g | L_g | B1_g (slice g of each vector).  Device g assembles ITS scalars on its own default
+//                stream: h_g arrives from the device that ran compute_H (asynchronous peer copy behind it), w_L and w are read from the
+//                range of w that device g streamed from the input file itself, r w_g is scaled there.  The partial points are folded in
+//                rank order like those of any sharded MSM.
 template <int CURVE>
-static std::shared_ptr<PendingMsm> start_fused_c(typename HIP_B::groth16_params* p, const uint64_t* h, const uint64_t* w_L, const uint64_t* w, const uint64_t* r) {
+static std::shared_ptr<PendingMsm> start_fused_c(typename HIP_B::groth16_params* p, const ScalarSource& h, const ScalarSource& w_L, const ScalarSource& w, const uint64_t* r) {
   const size_t d = p->d, m = p->m, n = d + 2 * m;
-  auto sc = std::make_shared<DeviceBuffer>(96 * n);
-  uint64_t* s = reinterpret_cast<uint64_t*>(sc->ptr);
-  check(mnt753_copy_d2d(s, h, 96 * d), "mnt753_copy_d2d");
-  check(mnt753_copy_d2d(s + 12 * d, w_L, 96 * (m - 1)), "mnt753_copy_d2d");
-  check(mnt753_vec_scale(CURVE, s + 12 * (d + m - 1), w, r, m + 1, nullptr), "mnt753_vec_scale");
-  auto pend = start_sharded(*p->HLB, ScalarSource{[s]() { return (const uint64_t*)s; }, nullptr, 0}, n, "mnt753_msm_start(C)");
-  pend->scalars = sc;
-  if (const char* e = getenv("MNT753_TRACE")) { if (atoi(e)) fprintf(stderr, "mnt753: C = Ht + Lt + r Bt1 as one MSM over H | L | B1 (%zu points)\n", n); }
+  ShardedBases& sb = *p->HLB;
+  if (const char* e = getenv("MNT753_TRACE")) { if (atoi(e)) fprintf(stderr, "mnt753: C = Ht + Lt + r Bt1 as one MSM over H | L | B1 (%zu points, %zu device%s)\n", n, sb.parts.size(), sb.parts.size() > 1 ? "s" : ""); }
+  if (!sb.interleaved) {
+    auto sc = std::make_shared<DeviceBuffer>(96 * n);
+    uint64_t* s = reinterpret_cast<uint64_t*>(sc->ptr);
+    fetch_into(h, 0, 0, d, s);
+    fetch_into(w_L, 0, 0, m - 1, s + 12 * d);
+    const uint64_t* wp = resident_on(w, 0, 0, m + 1);
+    if (!wp) { fetch_into(w, 0, 0, m + 1, s + 12 * (d + m - 1)); wp = s + 12 * (d + m - 1); }
+    check(mnt753_vec_scale(CURVE, s + 12 * (d + m - 1), wp, r, m + 1, nullptr), "mnt753_vec_scale");
+    auto pend = start_sharded(sb, ScalarSource{[s]() { return (const uint64_t*)s; }, 0, nullptr, 0}, n, "mnt753_msm_start(C)");
+    pend->scalars = sc;
+    return pend;
+  }
+  auto pend = std::make_shared<PendingMsm>();
+  const int n_dev = (int)sb.parts.size();
+  pend->sets.resize((size_t)n_dev);
+  const ScalarSource* srcs[3] = {&h, &w_L, &w};
+  for (int k = 0; k < n_dev; ++k) {
+    const int g = k + 1 < n_dev ? k + 1 : 0;   // device 0 (the one compute_H ran on) last
+    ShardedBases::Part& part = sb.parts[(size_t)g];
+    const size_t total = part.hi - part.lo;
+    if (total == 0) continue;
+    DeviceScope on(g);
+    if (!part.scalars || part.scalars->bytes < 96 * total) part.scalars = std::make_shared<DeviceBuffer>(96 * total);
+    uint64_t* s = reinterpret_cast<uint64_t*>(part.scalars->ptr);
+    size_t at = 0;
+    for (int v = 0; v < 3; ++v) {
+      const size_t lo = part.sub_lo[v], hi = part.sub_hi[v];
+      if (v < 2) fetch_into(*srcs[v], g, lo, hi, s + 12 * at);
+      else if (hi > lo) {
+        const uint64_t* wp = resident_on(w, g, lo, hi);
+        if (!wp) { fetch_into(w, g, lo, hi, s + 12 * at); wp = s + 12 * at; }
+        check(mnt753_vec_scale(CURVE, s + 12 * at, wp, r, hi - lo, nullptr), "mnt753_vec_scale");
+      }
+      at += hi - lo;
+    }
+    check(mnt753_msm_start(part.set->h, 0, s, 1, total, nullptr), "mnt753_msm_start(C)");
+    pend->sets[(size_t)g] = part.set;
+  }
+  pend->sets.erase(std::remove(pend->sets.begin(), pend->sets.end(), nullptr), pend->sets.end());
   return pend;
 }
 // Does the tree say Ht + Lt + r Bt1 -- in any association and order: exactly one unstarted MSM over each of H and L (unscaled) and B1
@@ -684,7 +860,8 @@ template <int CURVE> static std::shared_ptr<PendingMsm> try_fuse(const std::shar
   }
   auto* p = static_cast<typename HIP_B::groth16_params*>(terms[0].msm->owner);
   if (!p->HLB || t[1]->length != p->m + 1 || t[2]->length != p->m - 1 || t[3]->length != p->d) return nullptr;
-  return start_fused_c<CURVE>(p, t[3]->scalars(), t[2]->scalars(), t[1]->scalars(), r);
+  auto src = [](const LazyPoint* n) { return ScalarSource{n->scalars, n->home, n->slices.get(), n->offset}; };
+  return start_fused_c<CURVE>(p, src(t[3]), src(t[2]), src(t[1]), r);
 }
 // the plain way: every MSM on its own base set (built now if the parameters were loaded fused), one after the other
 template <int CURVE> static void lazy_value(LazyPoint& n, uint64_t* out) {
@@ -695,7 +872,7 @@ template <int CURVE> static void lazy_value(LazyPoint& n, uint64_t* out) {
       p->ensure_separate();
       ShardedBases& sb = n.which == 1 ? *p->B1 : (n.which == 2 ? *p->L : *p->H);
       typename HIP_B::G1 tmp;
-      tmp.pending = start_sharded(sb, ScalarSource{n.scalars, n.slices.get(), n.offset}, n.length, "mnt753_msm_start(G1)");
+      tmp.pending = start_sharded(sb, ScalarSource{n.scalars, n.home, n.slices.get(), n.offset}, n.length, "mnt753_msm_start(G1)");
       resolve_t<CURVE, MNT753_G1>(&tmp);
       memcpy(out, tmp.data, sizeof(tmp.data));
       return;
@@ -734,6 +911,7 @@ template <int CURVE> typename HIP_B::G1* HIP_B::multiexp_G1(vector_Fr* scalar_st
       n->keep = v;
       vector_Fr* vp = v.get();
       n->scalars = [vp]() { return (const uint64_t*)vp->ptr(); };
+      n->home = scalar_start->device();
       n->slices = scalar_start->slices;
       n->offset = scalar_start->offset;
       r->lazy = n;
@@ -763,7 +941,7 @@ template <int CURVE> typename HIP_B::G1* HIP_B::groth16_C(groth16_params* p, vec
   if (coefficients_for_H->size - coefficients_for_H->offset < d || w_L->size - w_L->offset < m - 1 || w->size - w->offset < m + 1)
     throw std::runtime_error("groth16_C: a scalar vector is shorter than its base vector");
   G1* out = new G1();
-  out->pending = start_fused_c<CURVE>(p, coefficients_for_H->ptr(), w_L->ptr(), w->ptr(), r->data);
+  out->pending = start_fused_c<CURVE>(p, source_of(coefficients_for_H), source_of(w_L), source_of(w), r->data);
   return out;
 }
 template <int CURVE> void HIP_B::fuse_C(bool on) { g_fused_c = on ? 1 : 0; }
@@ -776,10 +954,10 @@ template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_witness(const ch
   return new groth16_input(path, params->d, params->m, cs->data);
 }
 template <int CURVE> void HIP_B::delete_r1cs(r1cs* a) { delete a; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_w(groth16_input* in) { return new vector_Fr{in->w, in->n_w, 0, in->w_ready, in->w_slices}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_ca(groth16_input* in) { return new vector_Fr{in->ca, in->n_c, 0, in->ca_ready, nullptr}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cb(groth16_input* in) { return new vector_Fr{in->cb, in->n_c, 0, in->cb_ready, nullptr}; }
-template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cc(groth16_input* in) { return new vector_Fr{in->cc, in->n_c, 0, in->cc_ready, nullptr}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_w(groth16_input* in) { return new vector_Fr{in->w, in->n_w, 0, in->w_ready, in->w_slices, nullptr}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_ca(groth16_input* in) { return new vector_Fr{in->ca, in->n_c, 0, in->ca_ready, nullptr, nullptr}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cb(groth16_input* in) { return new vector_Fr{in->cb, in->n_c, 0, in->cb_ready, nullptr, nullptr}; }
+template <int CURVE> typename HIP_B::vector_Fr* HIP_B::input_cc(groth16_input* in) { return new vector_Fr{in->cc, in->n_c, 0, in->cc_ready, nullptr, nullptr}; }
 template <int CURVE> typename HIP_B::field* HIP_B::input_r(groth16_input* in) {
   field* f = new field();
   memcpy(f->data, in->r, 96);
@@ -803,23 +981,41 @@ template <int CURVE> static void warm_up(typename mnt753_hip_impl<CURVE>::groth1
   check(mnt753_copy_h2d(dev.ptr, host.data(), 96 * n), "mnt753_copy_h2d");
   std::vector<std::shared_ptr<PendingMsm>> pend;
   for (auto* sb : sets)
-    pend.push_back(start_sharded(*sb, ScalarSource{[&dev]() { return reinterpret_cast<const uint64_t*>(dev.ptr); }, nullptr, 0}, sb->n, "mnt753_msm_start(warm-up)"));
+    pend.push_back(start_sharded(*sb, ScalarSource{[&dev]() { return reinterpret_cast<const uint64_t*>(dev.ptr); }, 0, nullptr, 0}, sb->n, "mnt753_msm_start(warm-up)"));
   uint64_t sink[108];
   for (auto& pm : pend)
     for (auto& set : pm->sets) check(mnt753_msm_finish(set->h, sink), "mnt753_msm_finish(warm-up)");
 }
 template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const char* path) {
   groth16_params* p = new groth16_params(path);
+  const int n_dev = std::max(1, mnt753_device_count());
   auto dom = cached_domain<CURVE>(p->d + 1);
+  // a sharded prover transforms cb on device 1 and cc on device 2 (groth16_input): their tables are built now, like device 0's
+  for (int g = 1; g < std::min(n_dev, 3); ++g) (void)cached_domain<CURVE>(p->d + 1, g);
   warm_up<CURVE>(p);
-  // the buffers of one proof, allocated now and parked in the cache: w, ca, cb, cc, coefficients_for_H (device 0)
+  // the buffers of one proof, allocated now and parked in the cache: w, ca, cb, cc, coefficients_for_H, the scalars of groth16_C, and
+  // with several devices each device's range of w, its vector of compute_H and the staging of the transformed cb / cc on device 0
   {
     const size_t m_dom = mnt753_domain_size(dom->h);
     std::vector<std::unique_ptr<DeviceBuffer>> pre;
+    struct BackToDevice0 { int n; ~BackToDevice0() { if (n > 1) (void)mnt753_set_device(0); } } back{n_dev};
     pre.emplace_back(new DeviceBuffer(96 * (p->m + 1)));
-    for (int k = 0; k < 3; ++k) pre.emplace_back(new DeviceBuffer(96 * (p->d + 1)));
     pre.emplace_back(new DeviceBuffer(96 * (m_dom + 1)));
-    if (p->HLB) pre.emplace_back(new DeviceBuffer(96 * (p->d + 2 * p->m)));   // the scalars of groth16_C
+    if (n_dev == 1) {
+      for (int k = 0; k < 3; ++k) pre.emplace_back(new DeviceBuffer(96 * (p->d + 1)));
+      if (p->HLB) pre.emplace_back(new DeviceBuffer(96 * (p->d + 2 * p->m)));   // the scalars of groth16_C
+    } else {
+      pre.emplace_back(new DeviceBuffer(96 * (p->d + 1)));                                  // ca
+      for (int k = 0; k < 2; ++k) pre.emplace_back(new DeviceBuffer(96 * m_dom));           // staged cb, cc
+      if (n_dev == 2) pre.emplace_back(new DeviceBuffer(96 * (p->d + 1)));                  // cc stays on device 0
+      for (int g = 1; g < n_dev; ++g) {
+        check(mnt753_set_device(g), "mnt753_set_device");
+        size_t first, count;
+        groth16_input::w_range(p->m, n_dev, g, &first, &count);
+        pre.emplace_back(new DeviceBuffer(96 * count));
+        if (g <= 2) pre.emplace_back(new DeviceBuffer(96 * (p->d + 1)));                    // cb / cc
+      }
+    }
   }
   return p;
 }
@@ -858,15 +1054,41 @@ template <int CURVE> void HIP_B::groth16_output_write(G1* A, G2* B, G1* C, const
   fclose(out);
 }
 
+// compute_H<B> (cuda_prover_piecewise.cu:18-53) in device-resident calls.  All three vectors on one device: one call.  A sharded
+// prover keeps ca, cb, cc on three devices (groth16_input): each runs x <- cosetFFT(iFFT(x)) where its vector lives
+// (mnt753_compute_h_chain), the transformed cb and cc travel to ca's device (asynchronous peer copies, ordered behind the chains by
+// events), and the pointwise step, the last transform and coefficients_for_H happen there (mnt753_compute_h_finish).
 template <int CURVE> typename HIP_B::vector_Fr* HIP_B::compute_H_fused(evaluation_domain* domain, vector_Fr* ca, vector_Fr* cb, vector_Fr* cc) {
   const size_t m = mnt753_domain_size(domain->data->h);
-  auto h = std::make_shared<DeviceBuffer>(96 * (m + 1));
-  check(mnt753_compute_h(domain->data->h, ca->ptr(), cb->ptr(), cc->ptr(), reinterpret_cast<uint64_t*>(h->ptr), nullptr), "mnt753_compute_h");
-  return new vector_Fr{h, m + 1, 0, nullptr, nullptr};
+  const int da = ca->device(), db = cb->device(), dc = cc->device();
+  std::shared_ptr<DeviceBuffer> h;
+  { DeviceScope on(da); h = std::make_shared<DeviceBuffer>(96 * (m + 1)); }
+  vector_Fr* out = new vector_Fr{h, m + 1, 0, nullptr, nullptr, nullptr};
+  try {
+    if (da == db && da == dc) {
+      check(mnt753_compute_h(domain_on<CURVE>(domain, da), ca->ptr(), cb->ptr(), cc->ptr(), reinterpret_cast<uint64_t*>(h->ptr), nullptr), "mnt753_compute_h");
+      return out;
+    }
+    // the chains of the other devices first: device da is the one the rest of the proof waits for
+    if (db != da) check(mnt753_compute_h_chain(domain_on<CURVE>(domain, db), cb->ptr(), nullptr), "mnt753_compute_h_chain(cb)");
+    if (dc != da) check(mnt753_compute_h_chain(domain_on<CURVE>(domain, dc), cc->ptr(), nullptr), "mnt753_compute_h_chain(cc)");
+    check(mnt753_compute_h_chain(domain_on<CURVE>(domain, da), ca->ptr(), nullptr), "mnt753_compute_h_chain(ca)");
+    if (db == da) check(mnt753_compute_h_chain(domain_on<CURVE>(domain, da), cb->ptr(), nullptr), "mnt753_compute_h_chain(cb)");
+    if (dc == da) check(mnt753_compute_h_chain(domain_on<CURVE>(domain, da), cc->ptr(), nullptr), "mnt753_compute_h_chain(cc)");
+    std::vector<std::shared_ptr<DeviceBuffer>> keep;
+    const uint64_t* bp = operand_on(cb, da, m, keep);
+    const uint64_t* cp = operand_on(cc, da, m, keep);
+    check(mnt753_compute_h_finish(domain_on<CURVE>(domain, da), ca->ptr(), bp, cp, reinterpret_cast<uint64_t*>(h->ptr), nullptr), "mnt753_compute_h_finish");
+    keep_alive(out->keep, keep);
+    if (const char* e = getenv("MNT753_TRACE")) { if (atoi(e)) fprintf(stderr, "mnt753: compute_H over devices %d / %d / %d (chains where ca / cb / cc live, finish on %d)\n", da, db, dc, da); }
+  } catch (...) { delete out; throw; }
+  return out;
 }
 template <int CURVE> double HIP_B::input_load_seconds(groth16_input* in) {
-  in->cc_ready->wait();
-  return *in->load_seconds;
+  in->w_ready->wait(); in->ca_ready->wait(); in->cb_ready->wait(); in->cc_ready->wait();
+  if (in->w_slices) for (auto& sl : *in->w_slices) if (sl.ready) sl.ready->wait();
+  std::lock_guard<std::mutex> l(in->clock->mu);
+  return in->clock->secs;
 }
 template <int CURVE> const uint64_t* HIP_B::G1_words(const G1* a) { resolve<CURVE>(const_cast<G1*>(a)); return a->data; }
 template <int CURVE> const uint64_t* HIP_B::G2_words(const G2* a) { resolve<CURVE>(const_cast<G2*>(a)); return a->data; }

@@ -82,3 +82,54 @@ def msm_sharded(api, curve, group, local_partial, device=None):
         return np.ascontiguousarray(local_partial, dtype=np.uint64)
     parts = all_gather_points(local_partial, device)
     return fold_partials(api, curve, group, parts)
+
+
+# ---- compute_H over the ranks of a sharded prover ----------------------------------------------------------------------------------
+# The FFT is not sharded, but ca, cb and cc are independent until the pointwise step (cuda_prover_piecewise.cu:24-34): ranks 0 / 1 / 2
+# each stream ONE of them from the input file and run x <- cosetFFT(iFFT(x)) on it, the transformed cb and cc travel to rank 0
+# (send / recv: RCCL over xGMI), rank 0 runs the pointwise step and the last transform and hands slice g of coefficients_for_H to
+# rank g (the slice of H its MSM multiplies).  Two real exchange steps of the path, both point-to-point.
+def h_vector_home(world):
+    """rank that loads and transforms ca / cb / cc (rank 0 takes cc too when there are only two ranks)"""
+    return {"ca": 0, "cb": 1 if world > 1 else 0, "cc": 2 if world > 2 else 0}
+
+
+def _send(dist, t, dst, via_host):
+    dist.send(t.cpu().contiguous() if via_host else t.contiguous(), dst)
+
+
+def _recv(dist, t, src, via_host):
+    if via_host:
+        import torch
+        tmp = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(tmp, src)
+        t.copy_(tmp)
+    else:
+        dist.recv(t, src)
+
+
+def gather_chained_to_rank0(dist, rank, world, vec, via_host=False):
+    """vec: dict name -> int64 tensor of 12 * (d + 1) words; rank 0 holds all three (its own chained, the others to be filled), ranks
+    1 / 2 their own chained vector.  After the call rank 0 holds the three chained vectors."""
+    home = h_vector_home(world)
+    for k in ("cb", "cc"):
+        if home[k] != 0:
+            if rank == home[k]:
+                _send(dist, vec[k], 0, via_host)
+            elif rank == 0:
+                _recv(dist, vec[k], home[k], via_host)
+
+
+def scatter_h_slices(dist, rank, world, d, h_full, h_mine, via_host=False):
+    """rank 0: h_full = coefficients_for_H (>= 12 * d words).  Every rank receives words of its slice [lo, hi) of d into h_mine."""
+    lo, hi = shard_range(d, rank, world)
+    if rank == 0:
+        for g in range(1, world):
+            glo, ghi = shard_range(d, g, world)
+            if ghi > glo:
+                _send(dist, h_full[12 * glo:12 * ghi], g, via_host)
+        if hi > lo:
+            h_mine[:12 * (hi - lo)].copy_(h_full[12 * lo:12 * hi])
+    elif hi > lo:
+        _recv(dist, h_mine[:12 * (hi - lo)], 0, via_host)
+    return lo, hi

@@ -31,6 +31,20 @@ def group(curve, grp):
     return out
 
 
+def extfield(curve):
+    """-> array [24, 7, DEG * 12]: a, b, a*b, a^2, a^-1, a+b, a-b in Fq2 (MNT4753) / Fq3 (MNT6753)"""
+    w = 12 * (2 if curve == 0 else 3)
+    return _load(f"extfield_{CURVE_TAG[curve]}.bin").reshape(24, 7, w)
+
+
+def groupkat(curve, grp):
+    """-> list of dicts P, Q, sum (P+Q), dbl (2P), dbl_madd (2P + Q, mixed_add), dbl_add3 (2P + 3Q), diff (P-Q); all affine"""
+    aw = aff_words(curve, grp)
+    raw = _load(f"groupkat_{CURVE_TAG[curve]}_g{grp}.bin").reshape(16, 7, aw)
+    keys = ("P", "Q", "sum", "dbl", "dbl_madd", "dbl_add3", "diff")
+    return [dict(zip(keys, rec)) for rec in raw]
+
+
 def msm(curve, grp, n):
     aw = aff_words(curve, grp)
     raw = _load(f"msm_{CURVE_TAG[curve]}_g{grp}_{n}.bin")
@@ -57,6 +71,12 @@ def h(curve, logm):
     raw = _load(f"h_{CURVE_TAG[curve]}_{logm}.bin")
     ca, cb, cc = (raw[i * 12 * m:(i + 1) * 12 * m].reshape(m, 12) for i in range(3))
     return ca, cb, cc, raw[3 * 12 * m:].reshape(m + 1, 12)
+
+
+def e2e_fast_mnt6_paths():
+    """the reference generator's own `fast` size for MNT6753 (generate_parameters.cpp:127-133, log2_d = 10) and the proof the
+    reference's ./main wrote for it"""
+    return tuple(os.path.join(GOLDEN, f"e2e_mnt6_2p10_{k}.bin") for k in ("params", "input", "output"))
 
 
 def e2e_paths(curve):

@@ -20,6 +20,7 @@ def lib():
         u64p, sz, i = C.POINTER(C.c_uint64), C.c_size_t, C.c_int
         L.oracle_field_op.argtypes = [i, i, u64p, u64p, u64p]
         L.oracle_point_op.argtypes = [i, i, i, u64p, u64p, u64p]
+        L.oracle_ext_op.argtypes = [i, i, u64p, u64p, u64p]
         L.oracle_msm.argtypes = [i, i, u64p, u64p, sz, sz, u64p]
         L.oracle_fft.argtypes = [i, i, u64p, sz]
         L.oracle_divide_by_z_on_coset.argtypes = [i, u64p, sz]
@@ -58,6 +59,14 @@ def neg_fq(curve, y):
     if y.ndim == 1:
         return field_op(mod, 5, y)
     return np.stack([field_op(mod, 5, row) for row in y])
+
+
+def ext_op(curve, op, a, b=None):
+    """Fq2 (MNT4753) / Fq3 (MNT6753) element operation of the oracle: op 0 mul, 1 sqr, 2 inv, 3 add, 4 sub, 5 neg."""
+    a = _arr(a); out = np.zeros_like(a)
+    bb = _arr(b) if b is not None else np.zeros_like(a)
+    assert lib().oracle_ext_op(curve, op, _p(a), _p(bb), _p(out)) == 0
+    return out
 
 
 def point_op(curve, group, op, p, q=None):

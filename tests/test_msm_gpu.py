@@ -1,6 +1,8 @@
 """GPU: MSM parity -- HIP path (through the C ABI) vs the reference's golden vectors, vs the CPU oracle on seeded
 inputs, and at full size through the known discrete logs of the synthetic bases.  Bit-exact (integer work)."""
+import json
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -179,6 +181,35 @@ def test_full_size_2pow20_g1_mnt4753(gpu):
     lhs = gpu.point_to_affine(0, 1, gpu.point_add(0, 1, ms, mt))
     assert np.array_equal(lhs, gpu.point_to_affine(0, 1, mst))
     bs.close()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.skipif(os.environ.get("MNT753_SKIP_LIBFF_FULL") == "1", reason="opted out: ~25 s on 256 host threads, minutes on a small host")
+def test_full_size_2pow20_g1_vs_libff_multi_exp(gpu, tmp_path):
+    """BASELINE config[1] against the reference itself: ALL 2^20 (base, scalar) pairs through libff's own
+    multi_exp_with_mixed_addition<BDLO12> (oracle/_ref/ref_msm_bench = our driver around the reference's multiexp.tcc:443-496, compiled
+    by oracle/build_ref.sh; chunks = host threads as B::multiexp_G1 runs it) -- the check bench.py's cpu_baseline leg also makes, here
+    as a test.  The pairs carry what a real witness carries: zero and one scalars and an identity base."""
+    ref = os.path.join(O.ROOT, "oracle", "_ref", "ref_msm_bench")
+    if not os.access(ref, os.X_OK):
+        pytest.fail("oracle/_ref/ref_msm_bench is missing: build it in the container (make -C oracle ref); it travels with the snapshot")
+    n = 1 << 20
+    pts = gpu.synth_points(0, 1, 42, n)
+    sc = gpu.synth_scalars(0, 45, n)
+    sc[0] = gpu.api.mont_one(0); sc[1] = 0; sc[77] = 0; sc[n - 2] = gpu.api.mont_one(0)
+    pts[n - 1] = 0
+    path = tmp_path / "pairs.bin"
+    with open(path, "wb") as f:
+        pts.tofile(f); sc.tofile(f)
+    r = subprocess.run([ref, str(path), str(n)], capture_output=True, text=True, timeout=1400)
+    os.remove(path)
+    assert r.returncode == 0, r.stderr[-1000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    want = np.array([int(j["result_affine_hex"][16 * i:16 * i + 16], 16) for i in range(24)], dtype=np.uint64)
+    bs = gpu.BaseSet(0, 1, pts)
+    got = gpu.point_to_affine(0, 1, bs.msm(sc))
+    bs.close()
+    assert np.array_equal(got, want), "2^20-point G1 MSM differs from libff::multi_exp_with_mixed_addition on the same pairs"
 
 
 def test_large_g2_both_curves(gpu):

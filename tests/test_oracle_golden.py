@@ -33,6 +33,41 @@ def test_group_ops(curve, group):
 
 
 @pytest.mark.parametrize("curve", [0, 1])
+def test_extension_field_ops(curve):
+    """Fq2 / Fq3 of the oracle against libff's Fp2_model / Fp3_model (extfield_<curve>.bin, second capture of oracle/mint_golden.cpp)."""
+    for a, b, ab, sq, inv, s, d in G.extfield(curve):
+        assert np.array_equal(O.ext_op(curve, 0, a, b), ab)
+        assert np.array_equal(O.ext_op(curve, 1, a), sq)
+        assert np.array_equal(O.ext_op(curve, 2, a), inv)
+        assert np.array_equal(O.ext_op(curve, 3, a, b), s)
+        assert np.array_equal(O.ext_op(curve, 4, a, b), d)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("group", [1, 2])
+def test_group_law_kats(curve, group):
+    """operator+ / dbl / mixed_add of the reference's group classes: 16 cases per group with every side path (equal points, opposite
+    points, identities on either side, mixed addition that meets an equal / opposite point)."""
+    for r in G.groupkat(curve, group):
+        P2 = O.point_op(curve, group, 1, r["P"])
+        assert np.array_equal(O.point_op(curve, group, 0, r["P"], r["Q"]), r["sum"])
+        assert np.array_equal(P2, r["dbl"])
+        assert np.array_equal(O.point_op(curve, group, 0, P2, r["Q"]), r["dbl_madd"])
+        Q3 = O.point_op(curve, group, 0, O.point_op(curve, group, 1, r["Q"]), r["Q"])
+        assert np.array_equal(O.point_op(curve, group, 0, P2, Q3), r["dbl_add3"])
+        assert np.array_equal(O.point_op(curve, group, 2, r["P"], r["Q"]), r["diff"])
+
+
+def test_reference_generator_fast_set_mnt6753(tmp_path):
+    """The reference generator's own `fast` size for MNT6753 (generate_parameters.cpp:127-133: d + 1 = 2^10, 1.77 MB of files with the
+    generator's real R1CS-chain witness) and the proof the reference's ./main wrote for it."""
+    params, inp, expected = G.e2e_fast_mnt6_paths()
+    out = str(tmp_path / "proof.bin")
+    O.prove(1, params, inp, out)
+    assert filecmp.cmp(out, expected, shallow=False)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
 @pytest.mark.parametrize("group,n", [(1, n) for n in G.MSM_SIZES[1]] + [(2, n) for n in G.MSM_SIZES[2]])
 def test_msm(curve, group, n):
     bases, scalars, result = G.msm(curve, group, n)

@@ -43,6 +43,19 @@ def test_alternative_kernel_paths_write_the_same_proof(gpu, curve, env, tmp_path
     assert filecmp.cmp(out, expected, shallow=False)
 
 
+@pytest.mark.parametrize("flags,env", [([], {}), (["--ref-order", "--unfused-h"], {}), (["--unfused-c"], {}), (["--gpus", "2"], {"MNT753_SHARE_DEVICE": "1"}),
+                                       ([], {"MNT753_MSM_PAIR": "2", "MNT753_MSM_IRR": "1"})])
+def test_reference_generator_fast_set_mnt6753(gpu, flags, env, tmp_path):
+    """The reference generator's own `fast` size for MNT6753 (generate_parameters.cpp:127-133: d + 1 = 2^10) -- real keys and the real
+    R1CS-chain witness of generate_parameters, not the synthetic generator -- against the proof the reference's ./main wrote for it
+    (tests/golden/e2e_mnt6_2p10_*.bin, second capture of oracle/mint_golden.cpp)."""
+    params, inp, expected = G.e2e_fast_mnt6_paths()
+    out = str(tmp_path / "proof.bin")
+    r = subprocess.run([EXE, "MNT6753", "compute", params, inp, out] + flags, capture_output=True, text=True, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(out, expected, shallow=False)
+
+
 @pytest.mark.parametrize("curve,log2_d", [(0, 11), (1, 10)])
 def test_synthetic_set_vs_oracle(gpu, curve, log2_d, tmp_path):
     """MNT6753 at 2^10 is the reference's `generate_parameters fast` size."""
@@ -154,10 +167,16 @@ def test_sharded_inside_the_boundary(gpu, curve, n_dev, tmp_path):
     env = dict(os.environ, MNT753_SHARE_DEVICE="1")
     params, inp, expected = G.e2e_paths(curve)
     out = str(tmp_path / "proof.bin")
-    for flags in ([], ["--ref-order", "--unfused-h"]):
+    env["MNT753_TRACE"] = "1"
+    for flags in ([], ["--ref-order", "--unfused-h"], ["--ref-order"], ["--unfused-c"], ["--unfused-c", "--unfused-h", "--h-last"]):
         r = subprocess.run([EXE, NAME[curve], "compute", params, inp, out, "--gpus", str(n_dev)] + flags, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         assert filecmp.cmp(out, expected, shallow=False)
+        # round 4: ca / cb / cc are loaded and transformed on devices 0 / 1 / 2 (0 / 1 / 0 with two devices), not all on device 0
+        if "--unfused-h" not in flags:
+            assert f"compute_H over devices 0 / 1 / {2 if n_dev > 2 else 0}" in r.stderr, r.stderr[-800:]
+        if "--unfused-c" not in flags:
+            assert f"{n_dev} devices" in r.stderr and "one MSM over H | L | B1" in r.stderr, r.stderr[-800:]
     p2, i2 = str(tmp_path / "params"), str(tmp_path / "input")
     synth_files.write_files(gpu, curve, 11 - curve, p2, i2)
     o1, oN = str(tmp_path / "one.bin"), str(tmp_path / "many.bin")

@@ -1,0 +1,69 @@
+"""GPU: the exchange of the sharded MSM over RCCL on real hardware.
+
+The path has ONE exchange (multiexp.tcc:433-438 lifted to devices: one projective point per rank, then the serial fold).  The N > 1
+tests of this suite run it over gloo on a shared GPU; here torch.distributed's "nccl" backend -- RCCL on ROCm -- is initialised on the
+test box itself, at the only world size one GPU allows, and G1 / G2 / proof-sized blocks go through parallel.PointExchange's device
+path (pinned host -> device -> all_gather_into_tensor -> host).  Child process: a communicator that hangs must not take pytest down."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import json, os, socket, sys, time
+sys.path.insert(0, %(root)r)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np
+import torch
+import torch.distributed as dist
+from __graft_entry__ import load_package
+pkg = load_package()
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+device = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+pkg.init(0)
+res = {"librccl_mapped": any("librccl" in l for l in open("/proc/self/maps")), "blocks": {}}
+# a real partial result per group: a small MSM on this GPU, sent through the exchange and folded (world size 1: the fold is the identity)
+for curve, group in ((0, 1), (0, 2), (1, 1), (1, 2)):
+    pts = pkg.synth_points(curve, group, 11, 64)
+    sc = pkg.synth_scalars(curve, 12, 64)
+    bs = pkg.BaseSet(curve, group, pts)
+    local = bs.msm(sc)
+    bs.close()
+    total = pkg.parallel.msm_sharded(pkg.api, curve, group, local, device)     # world size 1: returns the local point without an exchange
+    parts = pkg.parallel.all_gather_points(local, device)                       # the exchange itself
+    assert len(parts) == 1 and np.array_equal(parts[0], local) and np.array_equal(total, local)
+    folded = pkg.parallel.fold_partials(pkg.api, curve, group, parts)
+    want = pkg.point_to_affine(curve, group, pkg.synth_expected_msm(curve, group, 11, sc))
+    assert np.array_equal(pkg.point_to_affine(curve, group, folded), want)
+    ex = pkg.parallel.PointExchange(len(local), device)
+    ts = []
+    for k in range(105):
+        t0 = time.perf_counter(); got = ex.all_gather(local); ts.append(time.perf_counter() - t0)
+    assert np.array_equal(got[0], local)
+    res["blocks"]["curve%%d_g%%d" %% (curve, group)] = {"words": int(len(local)), "mean_us": 1e6 * sum(ts[5:]) / 100, "min_us": 1e6 * min(ts[5:])}
+dist.destroy_process_group()
+print(json.dumps(res), flush=True)
+'''
+
+
+@pytest.mark.timeout(600)
+def test_point_exchange_over_rccl_world_size_1(gpu):
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": O.ROOT}], capture_output=True, text=True, timeout=540,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["librccl_mapped"], "torch.distributed's nccl backend did not map librccl"
+    assert set(res["blocks"]) == {"curve0_g1", "curve0_g2", "curve1_g1", "curve1_g2"}
+    for b in res["blocks"].values():
+        assert 0 < b["min_us"] <= b["mean_us"] < 1e6
+    print("RCCL world-1 exchange:", json.dumps(res["blocks"]))

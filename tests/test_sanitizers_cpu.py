@@ -42,6 +42,26 @@ def test_host_paths_clean_under_sanitizers(san, kind, curve, tmp_path):
 
 
 @pytest.mark.parametrize("kind", ["asan", "tsan"])
+def test_compute_h_spread_over_devices_clean_under_sanitizers(san, kind, tmp_path):
+    """Round 4: with several devices ca / cb / cc are streamed by the loader threads of devices 0 / 1 / 2 (0 / 1 / 0 with two), each
+    device transforms its own vector, cb and cc travel to device 0 for the pointwise step; every device assembles the scalars of its
+    part of H | L | B1 itself.  The loader threads, their latches (device 0 releases its range of w, then ca, then the rest of w) and
+    the staged peer copies under the sanitizers, for the fused call, the reference's B:: call sequence and uneven device counts."""
+    for curve in (0, 1):
+        params, inp, _ = G.e2e_paths(curve)
+        out = str(tmp_path / "o")
+        for n_dev, flags in ((2, []), (3, []), (5, ["--repeat", "2"]), (8, ["--ref-order"]), (2, ["--unfused-h", "--unfused-c"]), (3, ["--ref-order", "--unfused-h"]),
+                             (4, ["--unfused-c", "--h-last"]), (3, ["--ref-order", "--touch-all"])):
+            env = dict(os.environ, MNT753_TRACE="1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
+            r = subprocess.run([san[kind], NAME[curve], "compute", params, inp, out, "--gpus", str(n_dev)] + flags, capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+            if "--unfused-h" not in flags:
+                assert f"compute_H over devices 0 / 1 / {2 if n_dev > 2 else 0}" in r.stderr, r.stderr[-800:]
+            if "--unfused-c" not in flags and "--touch-all" not in flags:
+                assert f"{n_dev} devices" in r.stderr, r.stderr[-800:]
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
 def test_resident_job_feed_clean_under_sanitizers(san, kind, tmp_path):
     """main_hip --serve: jobs read from stdin against resident parameters, a failing job in the middle does not end the service."""
     params, inp, _ = G.e2e_paths(1)

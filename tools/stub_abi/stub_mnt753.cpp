@@ -46,7 +46,7 @@ template <class HC> int zero_t(uint64_t* o) { HPoint<HC>::zero().to_wire(o); ret
 #define CG(fn, ...) (curve == 0 ? (group == MNT753_G1 ? fn<HMnt4G1>(__VA_ARGS__) : fn<HMnt4G2>(__VA_ARGS__)) : (group == MNT753_G1 ? fn<HMnt6G1>(__VA_ARGS__) : fn<HMnt6G2>(__VA_ARGS__)))
 
 struct mnt753_bases { int curve, group, device; size_t n; void* copy; int pending; size_t pending_n; };
-struct mnt753_domain { int curve; size_t m; };
+struct mnt753_domain { int curve; size_t m; int device; };
 struct mnt753_r1cs { uint64_t num_inputs, m, nc; };
 
 extern "C" {
@@ -120,7 +120,7 @@ int mnt753_point_to_affine(int curve, int group, const uint64_t* p, uint64_t* o)
 int mnt753_point_from_affine(int curve, int group, const uint64_t* a, uint64_t* o) { if (bad_cg(curve, group)) return fail(MNT753_EINVAL, "point_from_affine"); return CG(from_aff_t, a, o); }
 int mnt753_domain_create(int curve, size_t m, mnt753_domain** out) {
   if (!out || curve < 0 || curve > 1 || m == 0 || (m & (m - 1))) return fail(MNT753_EDOMAIN, "domain_create: not a power of two");
-  *out = new mnt753_domain{curve, m}; return 0;
+  *out = new mnt753_domain{curve, m, t_dev}; return 0;
 }
 int mnt753_domain_free(mnt753_domain* d) { delete d; return 0; }
 size_t mnt753_domain_size(const mnt753_domain* d) { return d ? d->m : 0; }
@@ -134,6 +134,12 @@ int mnt753_compute_h(mnt753_domain* d, uint64_t* a, uint64_t* b, uint64_t* c, ui
   if (!d || !a || !b || !c || !h) return fail(MNT753_EINVAL, "compute_h: null");
   touch(a, d->m); touch(b, d->m); touch(c, d->m); memset(h, 0, 96 * (d->m + 1)); return 0;
 }
+int mnt753_compute_h_chain(mnt753_domain* d, uint64_t* v, void*) { if (!d || !v) return fail(MNT753_EINVAL, "compute_h_chain: null"); touch(v, d->m); return 0; }
+int mnt753_compute_h_finish(mnt753_domain* d, uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* h, void*) {
+  if (!d || !a || !b || !c || !h) return fail(MNT753_EINVAL, "compute_h_finish: null");
+  touch(a, d->m); touch(const_cast<uint64_t*>(b), d->m); touch(const_cast<uint64_t*>(c), d->m); memset(h, 0, 96 * (d->m + 1)); return 0;
+}
+int mnt753_domain_device(const mnt753_domain* d) { return d ? d->device : -1; }
 int mnt753_r1cs_create(int curve, uint64_t ni, uint64_t m, uint64_t nc, const uint64_t* const rp[3], const uint32_t* const col[3], const uint64_t* const cf[3], mnt753_r1cs** out) {
   if (curve < 0 || curve > 1 || !out || !rp || !col || !cf || ni > m) return fail(MNT753_EINVAL, "r1cs_create: bad argument");
   for (int k = 0; k < 3; ++k) for (uint64_t i = 0; i < rp[k][nc]; ++i) if (col[k][i] > m) return fail(MNT753_EINVAL, "r1cs_create: variable index out of range");
@@ -151,4 +157,6 @@ int mnt753_synth_points(int, int, uint64_t, size_t, uint64_t*, int) { return fai
 int mnt753_synth_scalars(int, uint64_t seed, size_t n, uint64_t* out) { for (size_t i = 0; i < 12 * n; ++i) out[i] = seed + i; return 0; }
 int mnt753_synth_expected_msm(int, int, uint64_t, size_t, const uint64_t*, uint64_t*) { return fail(MNT753_ENODEV, "stub"); }
 int mnt753_test_field_op(int, int, const uint64_t*, const uint64_t*, size_t, uint64_t*) { return fail(MNT753_ENODEV, "stub"); }
+int mnt753_test_ext_op(int, int, int, const uint64_t*, const uint64_t*, size_t, uint64_t*) { return fail(MNT753_ENODEV, "stub"); }
+int mnt753_test_point_op(int, int, int, int, const uint64_t*, const uint64_t*, size_t, uint64_t*) { return fail(MNT753_ENODEV, "stub"); }
 }
