@@ -588,6 +588,24 @@ def main():
             extras["fft_2p20_ms"] = ev_time(lambda: dom.fft(pkg.FFT, vecs[0].data_ptr(), stream=stream), 20)
             extras["fft_2p20_algorithmic_GBps"] = 192.0 * m / (extras["fft_2p20_ms"] * 1e-3) / 1e9
             extras["compute_h_2p20_ms"] = ev_time(lambda: dom.compute_h(vecs[0].data_ptr(), vecs[1].data_ptr(), vecs[2].data_ptr(), dh.data_ptr(), stream=stream), 5)
+            # the pieces of compute_H a sharded prover spreads over devices: one chain x <- cosetFFT(iFFT(x)) per
+            # vector, the joining step (pointwise + last transform), and the two loads device 0 still does before it can start
+            extras["compute_h_chain_2p20_ms"] = ev_time(lambda: dom.compute_h_chain(vecs[0].data_ptr(), stream=stream), 5)
+            extras["compute_h_finish_2p20_ms"] = ev_time(lambda: dom.compute_h_finish(vecs[0].data_ptr(), vecs[1].data_ptr(), vecs[2].data_ptr(), dh.data_ptr(), stream=stream), 5)
+            try:
+                with tempfile.NamedTemporaryFile(dir=os.environ.get("TMPDIR", "/tmp"), suffix=".bin") as f:
+                    blob = np.zeros(96 * (m + (m >> 3)) // 8, dtype=np.uint64)     # 100 MB (one vector) + 12.5 MB (an eighth of w)
+                    blob.tofile(f); f.flush()
+                    tl = []
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        buf = pkg.DeviceBuffer.from_file(f.name, 0, blob.nbytes)
+                        tl.append((time.perf_counter() - t0) * 1e3)
+                        buf.close()
+                    extras["input_load_112MB_ms"] = {"first": tl[0], "best": min(tl), "bytes": int(blob.nbytes),
+                                                     "note": "one loader lane, file in the page cache: the range of w + one vector of compute_H that device 0 of an 8-way split streams before its chain"}
+            except Exception as ex:
+                extras["input_load_112MB_ms"] = {"error": repr(ex)[:200]}
             dom.close(); del vecs, dh
             # BASELINE configs[2] as a roofline object of its own (192 B per element per transform = 96 B read +
             # 96 B written once).  One transform = three launches of k_ntt_group (8 + 8 + 4 butterfly stages on LDS tiles), i.e. three
@@ -677,22 +695,39 @@ def main():
                     sweep[f"{name}_G1_3x2p{(args.log_n if curve == 0 else 15) - shift}"] = {"ms": round(t, 3), "pair_levels": lv}
                     sweep_ok = sweep_ok and good
                 del p3, s3
-            # predicted prove time on N devices: the G2 MSM, A's MSM and the MSM for C of a slice back to back on its device (the point
-            # kernels own the whole chip: concurrency only fills launch gaps), compute_H on device 0 ahead of the
-            # slices of C, the O(1) host tail; MNT6753 with its own compute_H share (2^15: 0.3 ms)
+            # predicted prove time on N devices (re-derived in round 4 from pieces measured in THIS run on one GPU):
+            #   work bound  : device 0 runs its slices of the G2 MSM, of A's MSM and of the MSM for C back to back (the point kernels own
+            #                 the whole chip: concurrency only fills launch gaps) plus its share of compute_H -- all of it
+            #                 at N = 1; from N = 2 on one chain (two with two devices) and the joining step -- plus the O(1) host tail;
+            #   chain bound : what must happen in sequence before device 0's slice of C can start -- its range of w and ca over ITS PCIe
+            #                 link (measured: input_load_112MB_ms scaled by bytes), its chain, the arrival of the transformed cb / cc over
+            #                 xGMI (ASSUMED 2.0 ms for 100 MB, ~50 GB/s on one link: no multi-GPU hardware was available), the joining
+            #                 step -- then the slice of C.
+            # The prediction is the larger of the two.  MNT6753 with its own compute_H share (2^15: 0.3 ms).
             pred = {}
+            chain_ms, finish_ms = extras.get("compute_h_chain_2p20_ms", extras["compute_h_2p20_ms"] * 2 / 7), extras.get("compute_h_finish_2p20_ms", extras["compute_h_2p20_ms"] / 7)
+            ld = extras.get("input_load_112MB_ms", {})
+            load_ms_per_mb = (ld["best"] / (ld["bytes"] / 1e6)) if isinstance(ld, dict) and "best" in ld else 12.0 / 403.0
+            XGMI_100MB_MS = 2.0
             for N, shift in ((1, 0), (2, 1), (4, 2), (8, 3)):
                 g1 = sweep[f"MNT4753_G1_2p{args.log_n - shift}"]["ms"]; gg2 = sweep[f"MNT4753_G2_2p{args.log_n - shift}"]["ms"]
                 gc = sweep[f"MNT4753_G1_3x2p{args.log_n - shift}"]["ms"]
-                pred[f"MNT4753_2p20_{N}gpu_s"] = round((gg2 + g1 + gc + extras["compute_h_2p20_ms"] + 2.5) * 1e-3, 4)
+                h_dev0 = extras["compute_h_2p20_ms"] if N == 1 else (chain_ms * (2 if N == 2 else 1) + finish_ms)
+                work = gg2 + g1 + gc + h_dev0 + 2.5
+                in_mb = 403.0 if N == 1 else (100.7 / N + 100.7 * (2 if N == 2 else 1))
+                chain = in_mb * load_ms_per_mb + (extras["compute_h_2p20_ms"] if N == 1 else chain_ms * (2 if N == 2 else 1) + XGMI_100MB_MS + finish_ms) + gc + 2.5
+                pred[f"MNT4753_2p20_{N}gpu_s"] = round(max(work, chain) * 1e-3, 4)
+                pred[f"MNT4753_2p20_{N}gpu_bounds_ms"] = {"work_on_device_0": round(work, 2), "chain_to_C": round(chain, 2)}
                 h1 = sweep[f"MNT6753_G1_2p{15 - shift}"]["ms"]; h2 = sweep[f"MNT6753_G2_2p{15 - shift}"]["ms"]
                 hc = sweep[f"MNT6753_G1_3x2p{15 - shift}"]["ms"]
                 pred[f"MNT6753_2p15_{N}gpu_s"] = round((h2 + h1 + hc + 0.3 + 2.5) * 1e-3, 4)
             extras["slice_sweep_ms"] = sweep
             extras["slice_sweep_parity_ok"] = sweep_ok
-            extras["predicted_prove_s"] = dict(pred, model="G2 MSM + G1 MSM (A) + G1 MSM over 3 x the points (C = Ht + Lt + r Bt1 over H | L | B1) of one slice + compute_H "
-                                                     "(device 0) + 2.5 ms host tail and launch gaps; measured on ONE GPU at the slice sizes -- multi-GPU hardware was "
-                                                     "not available to the builder")
+            extras["predicted_prove_s"] = dict(pred, model="max(work bound, chain bound) per N -- work: G2 MSM + G1 MSM (A) + G1 MSM over 3 x the points (C over H_g | L_g | B1_g) of "
+                                                     "one slice + device 0's share of compute_H (all of it at N = 1; one chain + the joining step from N = 3, two chains at "
+                                                     "N = 2) + 2.5 ms host tail; chain: device 0's input over its own PCIe link + its chain + the transformed cb / cc over "
+                                                     "xGMI (ASSUMED 2.0 ms) + joining step + the slice of C.  Every piece but the xGMI copy measured on ONE GPU in this run; "
+                                                     "multi-GPU hardware was not available to the builder -- the curve itself is unmeasured")
             ok = ok and sweep_ok
             b2.close(); del g2
             line["extras"] = extras

@@ -95,9 +95,11 @@ MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   const uint64_t machine = machine_lanes(lanes_per_point);
   uint64_t lanes_target = machine * rounds;
   uint64_t T = (entries + lanes_target - 1) / lanes_target;
-  // floor of entries per lane: a lane's walk is sequential (one mixed addition after the other, ~50 us each), so a small MSM is as
-  // long as its T; below the floor fewer lanes run and fewer edge pieces are left to merge.  MNT753_MSM_TMIN overrides (development).
-  uint64_t t_min = 16;
+  // floor of entries per lane: a lane's walk is sequential (one mixed addition after the other, ~45 us each), so a small MSM is as
+  // long as its T, while more lanes mean more edge pieces to merge (one addition per bucket that straddles a lane boundary).  Round 4
+  // sweep with the tree merge (profiles/r04/small_msm_sweep.txt, MNT6753 G1): 2^12 points 1.96 / 1.62 / 1.61 ms at T = 16 / 8 / 4,
+  // 2^13 points 1.99 / 1.80 / 1.81; from 2^14 points on the natural T is above the floor.  MNT753_MSM_TMIN overrides (development).
+  uint64_t t_min = 8;
   if (const char* e = getenv("MNT753_MSM_TMIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) t_min = (uint64_t)v; }
   if (T < t_min) T = t_min;
   p.T = (uint32_t)T;
@@ -453,7 +455,7 @@ MsmPlan plan_for(const mnt753_bases* b, size_t n) {
   return p;
 }
 template <class V, class C>
-int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, uint32_t* acc_lanes) {
+int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, uint32_t* acc_lanes, uint32_t* acc_T, const uint32_t** acc_offs) {
   if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
     const int levels = p.pair_levels;
     // logical lanes: one workgroup per CU (the level kernels take 145 KB of LDS), 21 triples per wave for three-lane fields
@@ -568,9 +570,11 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
                          offs_acc, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
     }
     *acc_lanes = lanes_acc;
+    *acc_T = T2;
+    *acc_offs = offs_acc;
     return 0;
   } else {
-    (void)p; (void)n; (void)st; (void)d_aff; (void)b; (void)acc_lanes;
+    (void)p; (void)n; (void)st; (void)d_aff; (void)b; (void)acc_lanes; (void)acc_T; (void)acc_offs;
     return 0;
   }
 }
@@ -584,10 +588,12 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
   if (const char* e = getenv("MNT753_SPLIT_MASK")) mask = (unsigned)atoi(e);
   const int n_pair_levels = p.pair_levels;
   uint32_t acc_lanes = p.n_lanes;   // lanes the accumulate kernel ran with (= edge slots / 2)
+  uint32_t acc_T = p.T;             // entries per lane it was given, and the bucket offsets it walked (the last level's, behind pairing levels)
+  const uint32_t* acc_offs = b->d_offsets;
   g_last_pair_levels = n_pair_levels;
   g_last_irr_levels = n_pair_levels > 0 ? p.irr_levels : 0;
   if (n_pair_levels > 0) {
-    if (int rc = pair_and_accumulate<V, C>(p, n, st, d_aff, b, &acc_lanes)) return rc;
+    if (int rc = pair_and_accumulate<V, C>(p, n, st, d_aff, b, &acc_lanes, &acc_T, &acc_offs)) return rc;
   } else {
     if (mask & 1u)
       hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
@@ -597,7 +603,32 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
                          p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
   }
   HIP_TRY(hipEventRecord(b->ev[2], st));
-  {
+  // the edge pieces of the buckets that span several lanes: a K-ary tree over the lanes of every bucket (k_edge_tree_level; round 4),
+  // or the pointer-jumping merge of rounds 1-3 (MNT753_EDGE_TREE=0)
+  static const bool edge_tree = !(getenv("MNT753_EDGE_TREE") && atoi(getenv("MNT753_EDGE_TREE")) == 0);
+  if (edge_tree) {
+    const uint32_t n_slots = 2 * acc_lanes;
+    const unsigned gs = (n_slots + 255) / 256, gv = blocks_for<typename V::F>(n_slots);
+    const uint32_t blocked = n_pair_levels > 0 ? 1u : 0u;
+    // (T, lanes) the accumulate kernel ran with: its BLOCKED form takes T2 and derives the real share from the list's actual length
+    const uint32_t t_arg = n_pair_levels > 0 ? acc_T : p.T;
+    const uint32_t* offs = acc_offs;
+    HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));
+    uint32_t level = 0;
+    for (uint64_t stride = 1; stride < acc_lanes; stride *= EDGE_TREE_K, ++level) {
+      if (mask & 2u)
+        hipLaunchKernelGGL((k_edge_tree_level<V>), dim3(gv), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked,
+                           (uint32_t)stride, b->d_edge_flags, level);
+      else
+        hipLaunchKernelGGL((k_edge_tree_level<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked,
+                           (uint32_t)stride, b->d_edge_flags, level);
+    }
+    hipLaunchKernelGGL((k_edge_tree_finish<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked, b->d_buckets);
+    if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
+      if (n_pair_levels > 0)
+        hipLaunchKernelGGL((k_pair_fix<V>), dim3(blocks_for<typename V::F>(p.n_buckets)), dim3(256), 0, st, b->d_buckets, b->d_fix, b->d_gen, p.n_buckets);
+    }
+  } else {
     const uint32_t n_slots = 2 * acc_lanes;
     const unsigned gs = (n_slots + 255) / 256, gv = blocks_for<typename V::F>(n_slots);
     HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));

@@ -1410,6 +1410,75 @@ __global__ void __launch_bounds__(256) k_edge_finish(const uint32_t* __restrict_
   for (int k = 0; k < proj_words<C>() / 4; ++k) dst[k] = src[k];
 }
 
+// ---- edge merge as a tree over the lanes of a bucket (round 4) -----------------------------------------------------------------------
+// The pointer-jumping merge above is general but pays for it: 2 log2(slots) dependent launches (34 for 65536 lanes), every one of them
+// over ALL slots -- a wave runs the whole addition as soon as one of its slots has a partner, and half the partners are the identity
+// pieces that keep the slot list gap-free.  It was 1.6 of the 12.1 ms of an MNT6753 G2 MSM at 2^15 points and 0.4 of the 2.0 ms of a
+// 2^12-point G1 one.  But where the pieces of a bucket are is no secret: bucket b holds the entries [o0, o1) of the list, lane t walks the
+// entries [t T, (t + 1) T), so b has one piece in each of the lanes t_lo = o0 / T .. t_hi = (o1 - 1) / T -- the last run of lane t_lo
+// (its first run if the bucket starts exactly with the lane) and the first run of every later lane.  Piece i of the bucket = lane
+// t_lo + i.  A K-ary tree over i, in place: at level l (stride S = K^l) the piece with i % (K S) == 0 adds the pieces i + S, i + 2 S, ..
+// (at most K - 1 additions, one after the other) into its own slot; after ceil(log_K(pieces)) levels piece 0 holds the bucket.  Every
+// piece is read once per level it takes part in, a bucket inside one lane costs nothing, the common bucket (two lanes) one addition, and
+// there are ceil(log_K(lanes)) launches (6 for 65536 lanes with K = 8), all but the first of which leave at once unless some bucket
+// really spans more than K^l lanes (a device flag, as above) -- a witness full of ones still gets its deep tree.
+constexpr uint32_t EDGE_TREE_K = 8;
+// entries per lane the accumulate kernel really used (its BLOCKED form derives them from the actual length of the list)
+__device__ __forceinline__ uint32_t acc_entries_per_lane(uint32_t T, uint32_t n_lanes, uint32_t total, bool blocked) {
+  return blocked ? max((total + n_lanes - 1u) / n_lanes, min(T, 8u)) : T;
+}
+// slot of the piece lane t holds of the bucket that starts at entry o0 in lane t_lo
+__device__ __forceinline__ uint32_t edge_piece_slot(uint32_t t, uint32_t t_lo, uint32_t o0, uint32_t T) {
+  return (t == t_lo && (uint64_t)o0 > (uint64_t)t_lo * T) ? 2u * t + 1u : 2u * t;
+}
+template <class C>
+__global__ void __launch_bounds__(256, vm_waves<C>()) k_edge_tree_level(uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
+                                                           const uint32_t* __restrict__ offsets, uint32_t n_buckets, uint32_t T_arg, uint32_t n_lanes,
+                                                           uint32_t blocked, uint32_t stride, uint32_t* __restrict__ flags, uint32_t level) {
+  if (level > 0 && flags[level - 1] == 0) return;   // no bucket spans more than `stride` lanes: nothing left to do
+  const uint32_t sidx = logical_lane<typename C::F>();
+  if (sidx >= 2u * n_lanes) return;
+  const uint32_t b = edge_bucket[sidx];
+  if (b == EDGE_NONE) return;
+  const uint32_t T = acc_entries_per_lane(T_arg, n_lanes, offsets[n_buckets], blocked != 0);
+  const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
+  const uint32_t t = sidx >> 1, t_lo = o0 / T, t_hi = (o1 - 1u) / T;
+  if (t_hi == t_lo || edge_piece_slot(t, t_lo, o0, T) != sidx) return;   // a bucket inside one lane; the identity filler of a one-run lane
+  const uint32_t i = t - t_lo, k = t_hi - t_lo + 1u;
+  const uint64_t group = (uint64_t)stride * EDGE_TREE_K;
+  if (i % group != 0 || i + stride >= k) return;    // not the first piece of its group, or a group of one
+  Proj<C> acc, Q;
+  proj_load<C>(acc, edges + (size_t)sidx * proj_words<C>());
+  for (uint32_t j = 1; j < EDGE_TREE_K; ++j) {
+    const uint64_t ii = (uint64_t)i + (uint64_t)j * stride;
+    if (ii >= k) break;
+    const uint32_t slot = edge_piece_slot(t_lo + (uint32_t)ii, t_lo, o0, T);
+    proj_load<C>(Q, edges + (size_t)slot * proj_words<C>());
+    const int pc = add_pc<C>(acc, Q);
+    pt_vm<C, true>(acc, Q, pc);
+  }
+  proj_store<C>(edges + (size_t)sidx * proj_words<C>(), acc);
+  if (i == 0 && (uint64_t)k > group) flags[level] = 1;   // this bucket needs another level
+}
+// piece 0 of every bucket that left pieces in the edge slots now holds its sum
+template <class C>
+__global__ void __launch_bounds__(256) k_edge_tree_finish(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
+                                                         const uint32_t* __restrict__ offsets, uint32_t n_buckets, uint32_t T_arg, uint32_t n_lanes,
+                                                         uint32_t blocked, uint32_t* __restrict__ buckets) {
+  const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= 2u * n_lanes) return;
+  const uint32_t b = edge_bucket[sidx];
+  if (b == EDGE_NONE) return;
+  const uint32_t T = acc_entries_per_lane(T_arg, n_lanes, offsets[n_buckets], blocked != 0);
+  const uint32_t o0 = offsets[b];
+  const uint32_t t = sidx >> 1, t_lo = o0 / T;
+  if (t != t_lo || edge_piece_slot(t, t_lo, o0, T) != sidx) return;
+  const uint4* src = reinterpret_cast<const uint4*>(edges + (size_t)sidx * proj_words<C>());
+  uint4* dst = reinterpret_cast<uint4*>(buckets + (size_t)b * proj_words<C>());
+#pragma unroll
+  for (int q = 0; q < proj_words<C>() / 4; ++q) dst[q] = src[q];
+}
+
 // ---- bucket reduction ------------------------------------------------------------------------------
 // sum_b (b + 1) B[b] over nb = 2^k buckets by HALVING, every step one group addition deep:
 //     A_0 = B,   A_{l+1}[j] = A_l[2j] + A_l[2j+1],   G_l = sum of the odd-indexed elements of A_l        (l = 0 .. k-1)
@@ -1663,7 +1732,7 @@ __global__ void __launch_bounds__(256, 1) k_edge_level_sum_pair(const uint32_t* 
 // + 2 squarings) in a straight line; identities pass through, equal points fall back to the VM (whose addition turns into its doubling).
 // A macro for the same reason as MNT753_MADD_LINE (k_reduce_step_line<Mnt4G1>: 4 spilled registers in place, 88 behind a force-inlined
 // function); declares `out`.  pt_add_line() wraps the same text for the test hook.
-#define MNT753_ADD_LINE(C_, F_, out_, P_, Q_)                                                                          \
+#define MNT753_ADD_LINE(C_, F_, out_, P_, Q_, RELOAD_)                                                                        \
   const bool zP = pt_is_zero(P_), zQ = pt_is_zero(Q_);                                                                 \
   typename F_::E x1z2, y1z2, z1z2, u, v, uu, vv, vvv, R, Aq, w;                                                        \
   F_::mul(x1z2, P_.X, Q_.Z);                                                                                           \
@@ -1684,12 +1753,13 @@ __global__ void __launch_bounds__(256, 1) k_edge_level_sum_pair(const uint32_t* 
   F_::mul(R, vvv, y1z2);                                                                                               \
   F_::sub(out_.Y, w, R);                                                                                               \
   F_::mul(out_.Z, vvv, z1z2);                                                                                          \
-  if (zP || zQ) out_ = zQ ? P_ : Q_;                                                                                   \
-  else if (same) { out_ = P_; pt_vm<C_, true>(out_, Q_, PC_ADD); }
+  if (zP || zQ || same) { RELOAD_; if (zP || zQ) out_ = zQ ? P_ : Q_; else { out_ = P_; pt_vm<C_, true>(out_, Q_, PC_ADD); } }
+// RELOAD_: statements that bring P_ and Q_ back (the kernel reads them from memory again, so that the two operands need not stay in
+// registers across the fourteen products for the sake of the rare identity / equal-points cases: with them alive the kernel spilled)
 template <class C>
 __device__ __forceinline__ void pt_add_line(Proj<C>& res, const Proj<C>& P, const Proj<C>& Q) {
   using F = typename C::F;
-  MNT753_ADD_LINE(C, F, out, P, Q)
+  MNT753_ADD_LINE(C, F, out, P, Q, (void)0)
   res = out;
 }
 // One lane per addition without the VM: the same formulas in a straight line (14 products), for the wide steps of a base field
@@ -1731,7 +1801,7 @@ __global__ void __launch_bounds__(256, 1) k_reduce_step_line(const uint32_t* __r
   Proj<C> P, Q;
   if (e0) pt_set_zero(P); else proj_load<C>(P, src + (size_t)i0 * PW);
   if (e1) pt_set_zero(Q); else proj_load<C>(Q, src + (size_t)i1 * PW);
-  MNT753_ADD_LINE(C, F, out, P, Q)
+  MNT753_ADD_LINE(C, F, out, P, Q, (e0 ? pt_set_zero(P) : proj_load<C>(P, src + (size_t)i0 * PW), e1 ? pt_set_zero(Q) : proj_load<C>(Q, src + (size_t)i1 * PW)))
   proj_store<C>(dst, out);
 }
 // the k + 1 points the host combines, per bucket set: out[set][0] = T = A_k[0], out[set][1 + l] = G_l
