@@ -7,7 +7,7 @@ HIPCC ?= hipcc
 HIPFLAGS := -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-result
 LIB   := $(PKG)/libmnt753_hip.so
 
-HIP_SRCS := mnt753_core.hip mnt753_msm.hip msm_sort.hip msm_inst_mnt4g1.hip msm_inst_mnt4g2.hip msm_inst_mnt6g1.hip msm_inst_mnt6g2.hip mnt753_fft.hip mnt753_synth.hip mnt753_testhooks.hip mnt753_r1cs.hip
+HIP_SRCS := mnt753_core.hip mnt753_msm.hip msm_sort.hip msm_inst_mnt4g1.hip msm_inst_mnt4g2.hip msm_inst_mnt6g1.hip msm_inst_mnt6g2.hip mnt753_fft.hip mnt753_synth.hip mnt753_testhooks.hip mnt753_r1cs.hip mnt753_exchange.hip
 HIP_OBJS := $(addprefix $(BUILD)/,$(HIP_SRCS:.hip=.o))
 HDRS := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.hip.h $(CSRC)/*.h include/*.h)
 
@@ -33,7 +33,7 @@ $(BUILD)/%.o: $(CSRC)/%.hip
 -include $(HIP_OBJS:.o=.d)
 
 $(LIB): $(HIP_OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -128,15 +128,48 @@ def exchange_probe_main():
     print(json.dumps(res), flush=True)
 
 
+def exchange_abi_probe_main():
+    """Child process of the N = 1 run: the same exchange INSIDE the C ABI (mnt753_exchange_points: ncclCommInitAll over the prover's
+    devices, one ncclAllGather per device in a group call; what `main_hip --fold rccl` uses).  No torch in this process."""
+    import numpy as np
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    pkg.init(0)
+    res = {}
+    for name, words in (("g1_point", 36), ("proof_block", 144)):
+        blk = np.arange(words, dtype=np.uint64) + 1
+        t0 = time.perf_counter()
+        got, us = pkg.api.exchange_points([blk])          # the first call builds the communicator
+        first = time.perf_counter() - t0
+        ts, inner = [], []
+        for _ in range(105):
+            t0 = time.perf_counter()
+            got, us = pkg.api.exchange_points([blk])
+            ts.append(time.perf_counter() - t0); inner.append(us)
+        assert np.array_equal(got[0], blk)
+        res[name] = {"words": words, "mean_us": 1e6 * sum(ts[5:]) / 100, "min_us": 1e6 * min(ts[5:]), "inside_the_call_mean_us": sum(inner[5:]) / 100}
+        if name == "g1_point":
+            res["communicator_setup_s"] = first
+    res["librccl_mapped"] = any("librccl" in l for l in open("/proc/self/maps"))
+    print(json.dumps(res), flush=True)
+
+
 def exchange_leg():
-    """Run the probe above as a child before this process touches the GPU; a failure is reported, never fatal."""
+    """Run the probes above as children before this process touches the GPU; a failure is reported, never fatal."""
+    out = _exchange_child("--exchange-probe", "world-size-1 RCCL communicator on one MI355X through torch.distributed: the software path of the exchange "
+                          "(pinned host -> device -> all_gather_into_tensor -> host), no xGMI hop")
+    out["inside_the_c_abi"] = _exchange_child("--exchange-probe-abi", "mnt753_exchange_points (ncclCommInitAll over the prover's devices, ncclAllGather in a group call): "
+                                              "what main_hip --fold rccl puts in front of the serial fold; one device here, no xGMI hop")
+    return out
+
+
+def _exchange_child(flag, note):
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-probe"], capture_output=True, text=True, timeout=300,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), flag], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode == 0 and lines:
-            return dict(json.loads(lines[-1]), world_size=1, note="world-size-1 RCCL communicator on one MI355X: the software path of the exchange "
-                        "(pinned host -> device -> all_gather_into_tensor -> host), no xGMI hop")
+            return dict(json.loads(lines[-1]), world_size=1, note=note)
         return {"error": (r.stderr or r.stdout)[-400:]}
     except Exception as ex:
         return {"error": repr(ex)[:300]}
@@ -348,9 +381,12 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure the HBM traffic of the dominant phase")
     ap.add_argument("--no-exchange", action="store_true", help="skip the RCCL exchange-latency leg")
     ap.add_argument("--exchange-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--exchange-probe-abi", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.exchange_probe:
         return exchange_probe_main()
+    if args.exchange_probe_abi:
+        return exchange_abi_probe_main()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_under_torchrun(args))

@@ -73,6 +73,15 @@ int mnt753_copy_peer(int dst_device, void* dev_dst, int src_device, const void* 
  * coefficients_for_H leave device 0 behind compute_H (cuda_prover_piecewise.cu:79-81) while the host goes on enqueueing.  An MSM
  * started afterwards on dst_device with stream == NULL (mnt753_msm_start) is ordered behind the copy. */
 int mnt753_copy_peer_async(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes);
+/* The exchange of a sharded MSM over RCCL ("Collective"): every logical device contributes `words` u64 -- its
+ * partial points, multiexp.tcc:417-431 lifted to devices --, host_in[g] being device g's block in host memory (where mnt753_msm_finish
+ * put it); afterwards host_out holds the n_devices blocks in rank order, ready for the serial fold of multiexp.tcc:433-438
+ * (mnt753_point_add).  A single-process communicator over the devices of mnt753_init_devices (ncclCommInitAll), one ncclAllGather per
+ * device in a group call, xGMI between the GPUs; librccl is loaded on first use.  MNT753_ENODEV if librccl cannot be loaded or the
+ * logical devices are not distinct GPUs (MNT753_SHARE_DEVICE).  The wrapper classes fold on the host by default -- a partial point
+ * arrives there anyway -- and take this path with MNT753_FOLD=rccl (main_hip --fold rccl). */
+int mnt753_exchange_points(const uint64_t* const* host_in, size_t words, uint64_t* host_out);
+double mnt753_exchange_last_us(void);   /* duration of the last exchange: staging, collective, copy back */
 const char* mnt753_last_error(void);
 /* number of words (uint64) of one element / point of the given kind */
 size_t mnt753_affine_words(int curve, int group);      /* 24, 48 (MNT4753 G2) or 72 (MNT6753 G2) */

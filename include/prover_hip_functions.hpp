@@ -111,6 +111,9 @@ public:
   // as libff cuts an MSM over OpenMP threads (multiexp.tcc:417-431); multiexp_G1 / multiexp_G2 run the slices concurrently
   // and fold the partial results in rank order (multiexp.tcc:433-438).  The FFTs stay on device 0.
   static void use_devices(int n);
+  // Where the partial points of a sharded multiexp meet: false (default) -- on the host, where mnt753_msm_finish leaves them anyway;
+  // true -- through an RCCL all-gather over the devices (mnt753_exchange_points, xGMI) before the fold.  Also MNT753_FOLD=rccl.
+  static void fold_over_rccl(bool on);
   // The step before the hot path: instead of reading ca / cb / cc from the input file (where the
   // reference's generator put them, generate_parameters.cpp:44-57), evaluate the constraint system on the assignment on the
   // device -- the first loop of r1cs_to_qap_witness_map (reductions/r1cs_to_qap/r1cs_to_qap.tcc:223-237).

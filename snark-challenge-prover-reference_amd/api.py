@@ -42,6 +42,8 @@ def lib():
         "mnt753_copy_peer": (i, [i, vp, i, vp, sz]),
         "mnt753_copy_peer_async": (i, [i, vp, i, vp, sz]),
         "mnt753_last_error": (C.c_char_p, []),
+        "mnt753_exchange_points": (i, [C.POINTER(vp), sz, u64p]),
+        "mnt753_exchange_last_us": (C.c_double, []),
         "mnt753_affine_words": (sz, [i, i]),
         "mnt753_projective_words": (sz, [i, i]),
         "mnt753_dev_alloc": (i, [C.POINTER(vp), sz]),
@@ -115,6 +117,17 @@ def _u64(a):
 
 def init(device=0):
     _check(lib().mnt753_init(int(device)), "mnt753_init")
+
+
+def exchange_points(blocks):
+    """all-gather of one block of u64 words per logical device over RCCL inside the boundary (mnt753_exchange_points);
+    returns (list of blocks in rank order, microseconds)."""
+    keep = [np.ascontiguousarray(b, dtype=np.uint64) for b in blocks]
+    words = keep[0].size
+    arr = (C.c_void_p * len(keep))(*[C.c_void_p(k.ctypes.data) for k in keep])
+    out = np.zeros(len(keep) * words, dtype=np.uint64)
+    _check(lib().mnt753_exchange_points(arr, words, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_exchange_points")
+    return [out[g * words:(g + 1) * words].copy() for g in range(len(keep))], float(lib().mnt753_exchange_last_us())
 
 
 def affine_words(curve, group):

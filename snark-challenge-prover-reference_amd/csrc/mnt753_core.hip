@@ -115,6 +115,7 @@ int require_device() {
   return 0;
 }
 int current_physical_device() { return g_ndev ? g_devs[t_cur_dev < g_ndev ? t_cur_dev : 0].phys : -1; }
+int physical_device_of(int logical) { return logical >= 0 && logical < g_ndev ? g_devs[logical].phys : -1; }
 }  // namespace mnt753
 
 using namespace mnt753;

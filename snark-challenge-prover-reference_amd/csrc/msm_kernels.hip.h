@@ -1411,18 +1411,19 @@ __global__ void __launch_bounds__(256) k_edge_finish(const uint32_t* __restrict_
 }
 
 // ---- edge merge as a tree over the lanes of a bucket (round 4) -----------------------------------------------------------------------
-// The pointer-jumping merge above is general but pays for it: 2 log2(slots) dependent launches (34 for 65536 lanes), every one of them
-// over ALL slots -- a wave runs the whole addition as soon as one of its slots has a partner, and half the partners are the identity
-// pieces that keep the slot list gap-free.  It was 1.6 of the 12.1 ms of an MNT6753 G2 MSM at 2^15 points and 0.4 of the 2.0 ms of a
-// 2^12-point G1 one.  But where the pieces of a bucket are is no secret: bucket b holds the entries [o0, o1) of the list, lane t walks the
-// entries [t T, (t + 1) T), so b has one piece in each of the lanes t_lo = o0 / T .. t_hi = (o1 - 1) / T -- the last run of lane t_lo
+// The pointer-jumping merge above is general but pays for it: 2 log2(slots) dependent launches (34 for 65536 lanes: a sum into a
+// temporary and a copy back per level), every one of them over ALL slots, and half the partners are the identity pieces that keep the
+// slot list gap-free.  But where the pieces of a bucket are is no secret: bucket b holds the entries [o0, o1) of the list, lane t walks
+// the entries [t T, (t + 1) T), so b has one piece in each of the lanes t_lo = o0 / T .. t_hi = (o1 - 1) / T -- the last run of lane t_lo
 // (its first run if the bucket starts exactly with the lane) and the first run of every later lane.  Piece i of the bucket = lane
-// t_lo + i.  A K-ary tree over i, in place: at level l (stride S = K^l) the piece with i % (K S) == 0 adds the pieces i + S, i + 2 S, ..
-// (at most K - 1 additions, one after the other) into its own slot; after ceil(log_K(pieces)) levels piece 0 holds the bucket.  Every
-// piece is read once per level it takes part in, a bucket inside one lane costs nothing, the common bucket (two lanes) one addition, and
-// there are ceil(log_K(lanes)) launches (6 for 65536 lanes with K = 8), all but the first of which leave at once unless some bucket
-// really spans more than K^l lanes (a device flag, as above) -- a witness full of ones still gets its deep tree.
-constexpr uint32_t EDGE_TREE_K = 8;
+// t_lo + i.  A tree over i, IN PLACE: at level l (stride S = K^l) the piece with i % (K S) == 0 adds the pieces i + S, i + 2 S, .. into
+// its own slot; after ceil(log_K(pieces)) levels piece 0 holds the bucket.  No temporary, no copy, every piece read once per level it
+// takes part in, a bucket inside one lane costs nothing, the common bucket (two lanes) one addition; the levels after the last useful
+// one leave at once (a device flag, as above).  K = 2: one addition deep per level, log2(lanes) launches (half the old count).  K = 8
+// (six launches) was measured first and lost wherever buckets span several lanes -- its K - 1 additions per level run one after the
+// other in one lane: MNT6753 G1 2^13 points with c = 14 (54 entries per bucket over ~7 lanes) 1.16 ms with pointer jumping, 3.9 ms with
+// K = 8 (profiles/r04/small_msm_window_width_k8_tree.txt) -- and a witness full of ones puts half the list into one bucket.
+constexpr uint32_t EDGE_TREE_K = 2;
 // entries per lane the accumulate kernel really used (its BLOCKED form derives them from the actual length of the list)
 __device__ __forceinline__ uint32_t acc_entries_per_lane(uint32_t T, uint32_t n_lanes, uint32_t total, bool blocked) {
   return blocked ? max((total + n_lanes - 1u) / n_lanes, min(T, 8u)) : T;

@@ -143,6 +143,7 @@ struct ShardedBases {
 // one MSM in flight on every slice of a sharded vector
 struct PendingMsm {
   std::vector<std::shared_ptr<BaseSetHolder>> sets;
+  std::vector<int> devs;                   // logical device of sets[k] (rank order)
   std::shared_ptr<DeviceBuffer> scalars;   // scalar vector assembled for this MSM alone (groth16_C): lives as long as the MSM does
 };
 // A G1 value that has not been computed yet.  With the concatenated base set H | L | B1 resident (fused parameters), the three
@@ -535,15 +536,49 @@ public:
 
 #define HIP_B mnt753_hip_impl<CURVE>
 
+// Where the partial points of a sharded MSM meet.  Default: on the host -- mnt753_msm_finish hands every partial point to the host
+// anyway (the tail of a bucket reduction is a host Horner), so the serial fold of multiexp.tcc:433-438 needs no collective.
+// MNT753_FOLD=rccl / B::fold_over_rccl(true) / main_hip --fold rccl: the blocks go through mnt753_exchange_points first -- an RCCL
+// all-gather over the devices' communicator (xGMI), the collective SURVEY.md section 8e names -- and are folded from what came back; its
+// latency is traced (MNT753_TRACE=1).  Where no communicator can exist (logical devices sharing one GPU, no librccl) the host fold runs.
+static int g_fold_rccl = -1;
+static bool fold_rccl() {
+  if (g_fold_rccl < 0) { const char* e = getenv("MNT753_FOLD"); g_fold_rccl = e && !strcmp(e, "rccl") ? 1 : 0; }
+  return g_fold_rccl != 0;
+}
 // collect the partial results of the slices and fold them in rank order (multiexp.tcc:433-438: final = final + partial[i])
 template <int CURVE, int GROUP, class P> static void resolve_t(P* p) {
   if (!p->pending) return;
-  bool have = false;
+  const size_t pw = mnt753_projective_words(CURVE, GROUP);
+  std::vector<std::vector<uint64_t>> parts;
   for (auto& set : p->pending->sets) {
-    uint64_t part[108];
-    check(mnt753_msm_finish(set->h, part), "mnt753_msm_finish");
-    if (!have) { memcpy(p->data, part, sizeof(uint64_t) * mnt753_projective_words(CURVE, GROUP)); have = true; }
-    else check(mnt753_point_add(CURVE, GROUP, p->data, part, p->data), "mnt753_point_add");
+    parts.emplace_back(108, 0);
+    check(mnt753_msm_finish(set->h, parts.back().data()), "mnt753_msm_finish");
+  }
+  const int n_dev = std::max(1, mnt753_device_count());
+  if (fold_rccl() && !parts.empty()) {
+    // one block per logical device (the identity where a device had no points), through the collective, back in rank order
+    uint64_t zero_aff[72] = {0}, ident[108];
+    check(mnt753_point_from_affine(CURVE, GROUP, zero_aff, ident), "mnt753_point_from_affine");
+    std::vector<const uint64_t*> in((size_t)n_dev, ident);
+    for (size_t k = 0; k < parts.size(); ++k) in[(size_t)p->pending->devs[k]] = parts[k].data();
+    std::vector<uint64_t> out((size_t)n_dev * pw);
+    const int rc = mnt753_exchange_points(in.data(), pw, out.data());
+    const bool trace = getenv("MNT753_TRACE") && atoi(getenv("MNT753_TRACE"));
+    if (rc == 0) {
+      if (trace) fprintf(stderr, "mnt753: partial points over RCCL: all-gather of %zu u64 x %d devices in %.1f us\n", pw, n_dev, mnt753_exchange_last_us());
+      parts.clear();
+      for (int g = 0; g < n_dev; ++g) parts.emplace_back(out.begin() + (size_t)g * pw, out.begin() + (size_t)(g + 1) * pw);
+    } else if (rc == MNT753_ENODEV) {
+      if (trace) fprintf(stderr, "mnt753: partial points folded on the host (%s)\n", mnt753_last_error());
+    } else {
+      fail("mnt753_exchange_points");
+    }
+  }
+  bool have = false;
+  for (auto& part : parts) {
+    if (!have) { memcpy(p->data, part.data(), sizeof(uint64_t) * pw); have = true; }
+    else check(mnt753_point_add(CURVE, GROUP, p->data, part.data(), p->data), "mnt753_point_add");
   }
   if (!have) {   // an empty MSM: the identity (0 : 1 : 0)
     uint64_t zero_aff[72] = {0};
@@ -756,6 +791,14 @@ static void fetch_into(const ScalarSource& src, int g, size_t lo, size_t hi, uin
   if (const uint64_t* p = resident_on(src, g, lo, hi)) check(mnt753_copy_d2d(dst, p, 96 * (hi - lo)), "mnt753_copy_d2d");
   else check(mnt753_copy_peer_async(g, dst, src.home, src.home_ptr() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
 }
+// sets[g] was filled per device (null where a device got no points): keep the non-empty ones in rank order with their device numbers
+static void compact_in_rank_order(PendingMsm& pm) {
+  std::vector<std::shared_ptr<BaseSetHolder>> sets;
+  pm.devs.clear();
+  for (size_t g = 0; g < pm.sets.size(); ++g)
+    if (pm.sets[g]) { sets.push_back(pm.sets[g]); pm.devs.push_back((int)g); }
+  pm.sets.swap(sets);
+}
 static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarSource& src, size_t length, const char* what) {
   auto pend = std::make_shared<PendingMsm>();
   const int n_dev = (int)sb.parts.size();
@@ -776,7 +819,7 @@ static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarS
     pend->sets[(size_t)g] = part.set;
   }
   // rank order for the fold (multiexp.tcc:433-438), whatever the order of enqueueing was
-  pend->sets.erase(std::remove(pend->sets.begin(), pend->sets.end(), nullptr), pend->sets.end());
+  compact_in_rank_order(*pend);
   return pend;
 }
 template <class V> static ScalarSource source_of(V* v) {
@@ -832,7 +875,7 @@ static std::shared_ptr<PendingMsm> start_fused_c(typename HIP_B::groth16_params*
     check(mnt753_msm_start(part.set->h, 0, s, 1, total, nullptr), "mnt753_msm_start(C)");
     pend->sets[(size_t)g] = part.set;
   }
-  pend->sets.erase(std::remove(pend->sets.begin(), pend->sets.end(), nullptr), pend->sets.end());
+  compact_in_rank_order(*pend);
   return pend;
 }
 // Does the tree say Ht + Lt + r Bt1 -- in any association and order: exactly one unstarted MSM over each of H and L (unscaled) and B1
@@ -945,6 +988,7 @@ template <int CURVE> typename HIP_B::G1* HIP_B::groth16_C(groth16_params* p, vec
   return out;
 }
 template <int CURVE> void HIP_B::fuse_C(bool on) { g_fused_c = on ? 1 : 0; }
+template <int CURVE> void HIP_B::fold_over_rccl(bool on) { g_fold_rccl = on ? 1 : 0; }
 
 template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_input(const char* path, groth16_params* params) {
   return new groth16_input(path, params->d, params->m);

@@ -67,3 +67,40 @@ def test_point_exchange_over_rccl_world_size_1(gpu):
     for b in res["blocks"].values():
         assert 0 < b["min_us"] <= b["mean_us"] < 1e6
     print("RCCL world-1 exchange:", json.dumps(res["blocks"]))
+
+
+NAME = {0: "MNT4753", 1: "MNT6753"}
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("curve", [0, 1])
+def test_fold_over_rccl_inside_the_boundary(gpu, curve, tmp_path):
+    """main_hip --fold rccl: the partial points of every multiexp go through mnt753_exchange_points -- a single-process RCCL communicator
+    over the prover's devices (ncclCommInitAll; one device on this box), one ncclAllGather per device in a group call -- before the fold of
+    multiexp.tcc:433-438; the proof bytes are the reference's and the trace names the collective and its latency.  With logical devices
+    sharing the one GPU no communicator can exist: the wrapper says so and folds on the host."""
+    import filecmp
+    import golden_io as G
+    exe = os.path.join(O.ROOT, "snark-challenge-prover-reference_amd", "main_hip")
+    params, inp, expected = G.e2e_paths(curve)
+    out = str(tmp_path / "proof.bin")
+    env = dict(os.environ, MNT753_TRACE="1")
+    r = subprocess.run([exe, NAME[curve], "compute", params, inp, out, "--fold", "rccl", "--repeat", "2"], capture_output=True, text=True, env=env, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert filecmp.cmp(out, expected, shallow=False)
+    assert "partial points over RCCL: all-gather of" in r.stderr, r.stderr[-1500:]
+    r = subprocess.run([exe, NAME[curve], "compute", params, inp, out, "--fold", "rccl", "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, MNT753_SHARE_DEVICE="1"), timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert filecmp.cmp(out, expected, shallow=False)
+    assert "folded on the host" in r.stderr and "share a GPU" in r.stderr, r.stderr[-1500:]
+
+
+def test_exchange_points_through_the_c_abi(gpu):
+    """mnt753_exchange_points on the one device of this box: the block comes back unchanged, the latency is reported."""
+    import numpy as np
+    blk = np.arange(108, dtype=np.uint64) * 3 + 1
+    for _ in range(3):
+        got, us = gpu.api.exchange_points([blk])
+    assert len(got) == 1 and np.array_equal(got[0], blk) and 0 < us < 1e6
+    print("mnt753_exchange_points, one device: %.1f us" % us)

@@ -62,6 +62,21 @@ def test_compute_h_spread_over_devices_clean_under_sanitizers(san, kind, tmp_pat
 
 
 @pytest.mark.parametrize("kind", ["asan", "tsan"])
+def test_fold_over_the_exchange_clean_under_sanitizers(san, kind, tmp_path):
+    """--fold rccl: the partial points of every sharded multiexp go through mnt753_exchange_points (the stub copies them; with
+    MNT753_STUB_NO_RCCL=1 it refuses like a box without librccl and the wrapper falls back to the host fold)."""
+    params, inp, _ = G.e2e_paths(0)
+    out = str(tmp_path / "o")
+    for n_dev, extra_env, expect in ((1, {}, "over RCCL"), (3, {}, "over RCCL"), (8, {}, "over RCCL"), (2, {"MNT753_STUB_NO_RCCL": "1"}, "folded on the host")):
+        env = dict(os.environ, MNT753_TRACE="1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1", **extra_env)
+        r = subprocess.run([san[kind], "MNT4753", "compute", params, inp, out, "--gpus", str(n_dev), "--fold", "rccl", "--repeat", "2"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        assert expect in r.stderr, r.stderr[-800:]
+    r = run(san[kind], ["MNT4753", "compute", params, inp, out, "--gpus", "2", "--fold", "host"])
+    assert "over RCCL" not in r.stderr
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
 def test_resident_job_feed_clean_under_sanitizers(san, kind, tmp_path):
     """main_hip --serve: jobs read from stdin against resident parameters, a failing job in the middle does not end the service."""
     params, inp, _ = G.e2e_paths(1)

@@ -58,6 +58,14 @@ int mnt753_get_device(void) { return t_dev; }
 int mnt753_copy_peer(int, void* d, int, const void* s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int mnt753_copy_peer_async(int dd, void* d, int sd, const void* s, size_t n) { if (dd < 0 || dd >= g_ndev || sd < 0 || sd >= g_ndev) return fail(MNT753_EINVAL, "copy_peer_async: bad device"); if (n) memcpy(d, s, n); return 0; }
 const char* mnt753_last_error(void) { return t_err.c_str(); }
+// the exchange: a plain copy (the stub's "devices" are host memory); MNT753_STUB_NO_RCCL=1 plays a box without librccl
+int mnt753_exchange_points(const uint64_t* const* in, size_t words, uint64_t* out) {
+  if (!in || !out || !words) return fail(MNT753_EINVAL, "exchange_points: bad argument");
+  if (getenv("MNT753_STUB_NO_RCCL")) return fail(MNT753_ENODEV, "exchange_points: cannot load librccl (stub)");
+  for (int g = 0; g < g_ndev; ++g) { if (!in[g]) return fail(MNT753_EINVAL, "exchange_points: null block"); memcpy(out + words * (size_t)g, in[g], 8 * words); }
+  return 0;
+}
+double mnt753_exchange_last_us(void) { return 1.0; }
 size_t mnt753_affine_words(int curve, int group) { return bad_cg(curve, group) ? 0 : (size_t)24 * deg_of(curve, group); }
 size_t mnt753_projective_words(int curve, int group) { return bad_cg(curve, group) ? 0 : (size_t)36 * deg_of(curve, group); }
 int mnt753_dev_alloc(void** p, size_t n) { if (!g_ndev) return fail(MNT753_ENODEV, "no device"); *p = malloc(n ? n : 16); return *p ? 0 : fail(MNT753_ENOMEM, "alloc"); }
