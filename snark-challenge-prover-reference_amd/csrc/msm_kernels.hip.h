@@ -1410,6 +1410,12 @@ __global__ void __launch_bounds__(256) k_edge_finish(const uint32_t* __restrict_
   for (int k = 0; k < proj_words<C>() / 4; ++k) dst[k] = src[k];
 }
 
+// the VM's addition as a real call: its registers are then not part of the caller's allocation (the rare equal-points case of the
+// two-lane addition: inlined, the three-lane kernels spilled 500 registers and the step ran 2.4x slower than through the VM; the tree
+// level of the edge merge: see there)
+template <class C>
+__device__ __attribute__((noinline)) void pt_vm_add_outlined(Proj<C>& P, const Proj<C>& Q, int pc) { pt_vm<C, true>(P, Q, pc); }
+
 // ---- edge merge as a tree over the lanes of a bucket (round 4) -----------------------------------------------------------------------
 // The pointer-jumping merge above is general but pays for it: 2 log2(slots) dependent launches (34 for 65536 lanes: a sum into a
 // temporary and a copy back per level), every one of them over ALL slots, and half the partners are the identity pieces that keep the
@@ -1446,19 +1452,24 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_edge_tree_level(uint32_t
   const uint32_t t = sidx >> 1, t_lo = o0 / T, t_hi = (o1 - 1u) / T;
   if (t_hi == t_lo || edge_piece_slot(t, t_lo, o0, T) != sidx) return;   // a bucket inside one lane; the identity filler of a one-run lane
   const uint32_t i = t - t_lo, k = t_hi - t_lo + 1u;
-  const uint64_t group = (uint64_t)stride * EDGE_TREE_K;
-  if (i % group != 0 || i + stride >= k) return;    // not the first piece of its group, or a group of one
+  // The thread of piece i works as NODE i of this level: it sums the pieces K S i, K S i + S, .. into the first of them.  (A relabelling:
+  // "piece i works if i % (K S) == 0" is the same tree, but leaves one working lane in 2 K S slots -- from the third level on every
+  // wave over a long bucket carries a single addition and a level costs what the first one did; with the nodes packed at the front of
+  // the bucket's lane range the waves stay full and their number halves per level.)
+  const uint64_t group = (uint64_t)stride * EDGE_TREE_K, first = (uint64_t)i * group;
+  if (first + stride >= k) return;    // no such node, or a node of one piece
+  const uint32_t dst = edge_piece_slot(t_lo + (uint32_t)first, t_lo, o0, T);
   Proj<C> acc, Q;
-  proj_load<C>(acc, edges + (size_t)sidx * proj_words<C>());
+  proj_load<C>(acc, edges + (size_t)dst * proj_words<C>());
   for (uint32_t j = 1; j < EDGE_TREE_K; ++j) {
-    const uint64_t ii = (uint64_t)i + (uint64_t)j * stride;
+    const uint64_t ii = first + (uint64_t)j * stride;
     if (ii >= k) break;
     const uint32_t slot = edge_piece_slot(t_lo + (uint32_t)ii, t_lo, o0, T);
     proj_load<C>(Q, edges + (size_t)slot * proj_words<C>());
     const int pc = add_pc<C>(acc, Q);
-    pt_vm<C, true>(acc, Q, pc);
+    pt_vm_add_outlined<C>(acc, Q, pc);
   }
-  proj_store<C>(edges + (size_t)sidx * proj_words<C>(), acc);
+  proj_store<C>(edges + (size_t)dst * proj_words<C>(), acc);
   if (i == 0 && (uint64_t)k > group) flags[level] = 1;   // this bucket needs another level
 }
 // piece 0 of every bucket that left pieces in the edge slots now holds its sum
@@ -1584,10 +1595,6 @@ __device__ __forceinline__ PairGeom<F> pair_geometry() {
   }
   return g;
 }
-// the rare equal-points case of the two-lane addition: a real call, so that the VM's registers are not part of the common path's
-// allocation (inlined, the three-lane kernels spilled 500 registers and the step ran 2.4x slower than through the VM)
-template <class C>
-__device__ __attribute__((noinline)) void pt_vm_add_outlined(Proj<C>& P, const Proj<C>& Q, int pc) { pt_vm<C, true>(P, Q, pc); }
 // S + T with TWO point-lanes per addition.  The 12 products + 2 squarings of a projective addition are five dependency levels
 // deep; two halves run them as 3 + 1 + 2 + 1 + 1 = 8 sequential products: the odd half holds the operands swapped (S = its first
 // operand, T = its second), so the first level is the same code in both halves, later levels pick their operands by parity and
