@@ -240,7 +240,9 @@ int mnt753_test_ext_op(int curve, int split, int op, const uint64_t* a, const ui
  *     2 P + Q with Q affine (Q's Z is taken as 1 unless 0) through the VM's mixed addition (bucket accumulation);
  *     3 the same as straight-line code (bucket accumulation of the base fields and the two-lane Fq2; other fields: as op 2);
  *     4 P + Q with two point-lanes per addition (narrow steps of the bucket reduction, edge merge of Fq3);
- *     5 P + Q as straight-line code (wide steps of the bucket reduction, base fields; other fields: as op 0). */
+ *     5 P + Q as straight-line code (wide steps of the bucket reduction, base fields; other fields: as op 0);
+ *     6 P + Q with one GROUP of lanes per addition (8 for the base fields, 16 for Fq2 / Fq3: the narrowest steps of the bucket
+ *       reduction and the levels of the edge merge of a short lane list; split = 0 only). */
 int mnt753_test_point_op(int curve, int group, int split, int op, const uint64_t* p_proj, const uint64_t* q_proj, size_t n, uint64_t* out_proj);
 
 #ifdef __cplusplus

@@ -64,6 +64,7 @@ struct FieldFp2 {
   static constexpr int DEG = 2;
   static constexpr int LANES = 1;
   static constexpr int MOD = M;
+  static constexpr unsigned NONRES = NR;
   static HD void mul(E& r, const E& x, const E& y) {
     Fp<M> a, b, t, aA, bB, sx, sy;
     fp_add(sx, x.c0, x.c1);
@@ -108,6 +109,7 @@ struct FieldFp3 {
   static constexpr int DEG = 3;
   static constexpr int LANES = 1;
   static constexpr int MOD = M;
+  static constexpr unsigned NONRES = NR;
   static HD void mul(E& r, const E& x, const E& y) {
     Fp<M> a, b, t, aA, bB, cC, t_bc, t_ab, t_ac;
     Fp<M> x_bc, x_ab, x_ac, y_bc, y_ab, y_ac;

@@ -221,8 +221,51 @@ __global__ void __launch_bounds__(256, 1) k_point_op_pairlanes(const uint32_t* _
   if (pt_is_zero(out)) pt_set_zero(out);
   proj_store_wire<C>(out_wire + (size_t)i * PWW, out);
 }
+// op 6: P + Q with one group of lanes per addition (flow_add, msm_flow.hip.h: k_reduce_step_flow, k_edge_tree_level_flow).  The
+// kernels work on points in the device layout: conversion kernels either side.
+template <class C>
+__global__ void __launch_bounds__(256) k_wire_to_dev(const uint32_t* __restrict__ wire, uint32_t* __restrict__ dev, uint32_t n) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Proj<C> P;
+  proj_load_wire<C>(P, wire + (size_t)t * 72 * C::F::DEG);
+  proj_store<C>(dev + (size_t)t * proj_words<C>(), P);
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_dev_to_wire(const uint32_t* __restrict__ dev, uint32_t* __restrict__ wire, uint32_t n) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Proj<C> P;
+  proj_load<C>(P, dev + (size_t)t * proj_words<C>());
+  if (pt_is_zero(P)) pt_set_zero(P);
+  proj_store_wire<C>(wire + (size_t)t * 72 * C::F::DEG, P);
+}
+template <class C>
+int run_point_op_flow(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
+  using F = typename C::F;
+  if constexpr (F::LANES != 1) {
+    return set_error(MNT753_EINVAL, "test_point_op: the lane-group addition is instantiated with the one-lane configuration (split = 0)");
+  } else {
+    const size_t bytes = 288 * (size_t)F::DEG * n, dev_bytes = sizeof(uint32_t) * proj_words<C>() * n;
+    DevBuf wp, wq, wout, dp, dq, dout;
+    HIP_TRY(hipMalloc(&wp.p, bytes)); HIP_TRY(hipMalloc(&wq.p, bytes)); HIP_TRY(hipMalloc(&wout.p, bytes));
+    HIP_TRY(hipMalloc(&dp.p, dev_bytes)); HIP_TRY(hipMalloc(&dq.p, dev_bytes)); HIP_TRY(hipMalloc(&dout.p, dev_bytes));
+    HIP_TRY(hipMemcpy(wp.p, p, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(wq.p, q, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dout.p, 0, dev_bytes));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL((k_wire_to_dev<C>), dim3(gb), dim3(256), 0, 0, wp.p, dp.p, (uint32_t)n);
+    hipLaunchKernelGGL((k_wire_to_dev<C>), dim3(gb), dim3(256), 0, 0, wq.p, dq.p, (uint32_t)n);
+    hipLaunchKernelGGL((k_flow_add_list<C>), dim3((unsigned)((n + Flow<C>::PER_WAVE - 1) / Flow<C>::PER_WAVE)), dim3(64), 0, 0, dp.p, dq.p, dout.p, (uint32_t)n);
+    hipLaunchKernelGGL((k_dev_to_wire<C>), dim3(gb), dim3(256), 0, 0, dout.p, wout.p, (uint32_t)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, wout.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+  }
+}
 template <class C>
 int run_point_op(int op, const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
+  if (op == 6) return run_point_op_flow<C>(p, q, n, out);
   using F = typename C::F;
   const size_t bytes = 288 * (size_t)F::DEG * n;
   DevBuf dp, dq, dout;
@@ -255,7 +298,7 @@ extern "C" int mnt753_test_ext_op(int curve, int split, int op, const uint64_t* 
 }
 
 extern "C" int mnt753_test_point_op(int curve, int group, int split, int op, const uint64_t* p_proj, const uint64_t* q_proj, size_t n, uint64_t* out_proj) {
-  if (curve < 0 || curve > 1 || (group != MNT753_G1 && group != MNT753_G2) || op < 0 || op > 5 || (n && (!p_proj || !q_proj || !out_proj)) || n > 0x7fffffffu)
+  if (curve < 0 || curve > 1 || (group != MNT753_G1 && group != MNT753_G2) || op < 0 || op > 6 || (n && (!p_proj || !q_proj || !out_proj)) || n > 0x7fffffffu)
     return set_error(MNT753_EINVAL, "test_point_op: bad argument");
   if (split && group == MNT753_G1) return set_error(MNT753_EINVAL, "test_point_op: G1 has no lane-split form");
   if (int rc = require_device()) return rc;

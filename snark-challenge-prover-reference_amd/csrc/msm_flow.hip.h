@@ -273,45 +273,55 @@ __global__ void __launch_bounds__(64) k_reduce_step_flow(const uint32_t* __restr
   flow_add<C>(lds + gi * FL::GROUP_WORDS, l, src + (size_t)i0 * PW, src + (size_t)i1 * PW, e0, e1, dst, live);
 }
 
-// one level of the edge merge tree (k_edge_tree_level) with one GROUP per slot: the group of the slot that holds piece i of a bucket
-// works as node i of the level
+// The levels of the edge merge tree (k_edge_tree_level) on lane groups.  A group per SLOT would leave nearly every wave with one live
+// group among idle ones (the nodes of a level are a fifth of the slots or far fewer): measured on the MNT6753 G2 2^15 MSM, 533 us for a
+// level the VM does in 305.  So the nodes of a level are a LIST: k_edge_nodes writes the list of the first level that runs on groups
+// (one thread per slot, no arithmetic), every level appends the nodes of the next one as its own finish -- node i with i even becomes
+// node i / 2, same destination, the partner 2 S pieces on -- and a launch is sized for the most nodes its level can have; the blocks
+// past the end of the list leave after one scalar load.  Entry: (destination slot, partner slot, bucket, node index).
 template <class C>
-__global__ void __launch_bounds__(64) k_edge_tree_level_flow(uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
-                                                            const uint32_t* __restrict__ offsets, uint32_t n_buckets, uint32_t T_arg, uint32_t n_lanes,
-                                                            uint32_t blocked, uint32_t stride, uint32_t* __restrict__ flags, uint32_t level) {
+__global__ void __launch_bounds__(256) k_edge_nodes(const uint32_t* __restrict__ edge_bucket, const uint32_t* __restrict__ offsets, uint32_t n_buckets, uint32_t T_arg,
+                                                   uint32_t n_lanes, uint32_t blocked, uint32_t stride, const uint32_t* __restrict__ flags, uint32_t level,
+                                                   uint4* __restrict__ list, uint32_t* __restrict__ count) {
+  if (level > 0 && flags[level - 1] == 0) return;   // the levels before this one (slot-driven) found no bucket that needs it
+  const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= 2u * n_lanes) return;
+  const uint32_t b = edge_bucket[sidx];
+  if (b == EDGE_NONE) return;
+  const uint32_t T = acc_entries_per_lane(T_arg, n_lanes, offsets[n_buckets], blocked != 0);
+  const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
+  const uint32_t t = sidx >> 1, t_lo = o0 / T, t_hi = (o1 - 1u) / T;
+  if (t_hi == t_lo || edge_piece_slot(t, t_lo, o0, T) != sidx) return;
+  const uint32_t i = t - t_lo, kk = t_hi - t_lo + 1u;
+  const uint64_t first = (uint64_t)i * stride * EDGE_TREE_K;
+  if (first + stride >= kk) return;
+  const uint32_t pos = atomicAdd(count, 1u);
+  list[pos] = make_uint4(edge_piece_slot(t_lo + (uint32_t)first, t_lo, o0, T), edge_piece_slot(t_lo + (uint32_t)(first + stride), t_lo, o0, T), b, i);
+}
+template <class C>
+__global__ void __launch_bounds__(64) k_edge_tree_level_list(uint32_t* __restrict__ edges, const uint32_t* __restrict__ offsets, uint32_t n_buckets, uint32_t T_arg,
+                                                            uint32_t n_lanes, uint32_t blocked, uint32_t stride, const uint4* __restrict__ list_in,
+                                                            const uint32_t* __restrict__ count_in, uint4* __restrict__ list_out, uint32_t* __restrict__ count_out) {
   using FL = Flow<C>;
   __shared__ __attribute__((aligned(16))) uint32_t lds[FL::WAVE_WORDS];
-  if (level > 0 && flags[level - 1] == 0) return;   // no bucket spans more than `stride` lanes: nothing left to do
-  const uint32_t gi = threadIdx.x / FL::G, l = threadIdx.x - gi * FL::G;
-  const uint32_t sidx = blockIdx.x * FL::PER_WAVE + gi;
-  constexpr int PW = proj_words<C>();
-  bool act = sidx < 2u * n_lanes;
-  uint32_t dst = 0, slot = 0;
-  bool more = false;
-  if (act) {
-    const uint32_t b = edge_bucket[sidx];
-    act = b != EDGE_NONE;
-    if (act) {
-      const uint32_t T = acc_entries_per_lane(T_arg, n_lanes, offsets[n_buckets], blocked != 0);
-      const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
-      const uint32_t t = sidx >> 1, t_lo = o0 / T, t_hi = (o1 - 1u) / T;
-      act = t_hi != t_lo && edge_piece_slot(t, t_lo, o0, T) == sidx;
-      if (act) {
-        const uint32_t i = t - t_lo, kk = t_hi - t_lo + 1u;
-        const uint64_t group = (uint64_t)stride * EDGE_TREE_K, first = (uint64_t)i * group;
-        act = first + stride < kk;
-        if (act) {
-          dst = edge_piece_slot(t_lo + (uint32_t)first, t_lo, o0, T);
-          slot = edge_piece_slot(t_lo + (uint32_t)(first + stride), t_lo, o0, T);
-          more = i == 0u && (uint64_t)kk > group;
-        }
-      }
-    }
-  }
-  if (__ballot(act) == 0ull) return;                // the whole wave (= block) leaves together
   static_assert(EDGE_TREE_K == 2, "one partner per node");
-  flow_add<C>(lds + gi * FL::GROUP_WORDS, l, edges + (size_t)dst * PW, edges + (size_t)slot * PW, false, false, edges + (size_t)dst * PW, act);
-  if (more && l == 0u) flags[level] = 1;            // this bucket needs another level
+  const uint32_t n = *count_in;
+  if (blockIdx.x * FL::PER_WAVE >= n) return;       // past the end of the list (an empty list: a level nothing needs)
+  const uint32_t gi = threadIdx.x / FL::G, l = threadIdx.x - gi * FL::G;
+  const uint32_t item = blockIdx.x * FL::PER_WAVE + gi;
+  const bool act = item < n;
+  const uint4 node = act ? list_in[item] : make_uint4(0u, 0u, 0u, 1u);
+  constexpr int PW = proj_words<C>();
+  flow_add<C>(lds + gi * FL::GROUP_WORDS, l, edges + (size_t)node.x * PW, edges + (size_t)node.y * PW, false, false, edges + (size_t)node.x * PW, act);
+  if (!act || l != 0u || (node.w & 1u) != 0u) return;
+  // node i / 2 of the next level: this node's sum and the one 2 S pieces on, if the bucket reaches that far
+  const uint32_t T = acc_entries_per_lane(T_arg, n_lanes, offsets[n_buckets], blocked != 0);
+  const uint32_t o0 = offsets[node.z], o1 = offsets[node.z + 1];
+  const uint32_t t_lo = o0 / T, kk = (o1 - 1u) / T - t_lo + 1u;
+  const uint64_t first = (uint64_t)node.w * stride * 2u, partner = first + 2ull * stride;
+  if (partner >= kk) return;
+  const uint32_t pos = atomicAdd(count_out, 1u);
+  list_out[pos] = make_uint4(node.x, edge_piece_slot(t_lo + (uint32_t)partner, t_lo, o0, T), node.z, node.w >> 1);
 }
 
 // a list of independent additions out[i] = p[i] + q[i] (points in the device layout): the test hook's view of flow_add

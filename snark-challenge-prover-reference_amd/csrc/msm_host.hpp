@@ -207,7 +207,7 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_edges, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_bucket, sizeof(uint32_t) * 2 * (size_t)p.n_lanes));
   HIP_TRY(hipMalloc(&b->d_edge_tmp, sizeof(uint32_t) * PW * 2 * (size_t)p.n_lanes));
-  HIP_TRY(hipMalloc(&b->d_edge_flags, sizeof(uint32_t) * 40));
+  HIP_TRY(hipMalloc(&b->d_edge_flags, sizeof(uint32_t) * 128));   // 40 level flags, the node counts of the list-driven levels behind them
   // bucket reduction by halving (k_reduce_step): A_1 .. A_k and the ping-pong halves of the trees, nb points each per bucket
   // set; then the c points per set (T, G_0 .. G_{c-2}) the host combines
   HIP_TRY(hipMalloc(&b->d_part_a, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
@@ -235,7 +235,9 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
     // floors (and, for Fq3, the one width its sizes ever want) from the sweep: the bucket count at which one round of lanes holds
     // the whole reduction -- 2^17 buckets for the base fields and the two-lane Fq2, 2^13 for the three-lane Fq3 (MNT6753 G2 2^15:
     // 11.9 ms at c = 14 against 12.3-12.4 at 15 / 16; two-adicity 15 caps its size)
-    if (C::F::DEG == 1) pc = pick_precomp_bits(n, 8.0, 18);
+    // (round 4, with the narrow halving steps on lane groups at ~30 us each: 4096 base-field points 1.43 ms at 18 bits, 1.26 at 14 --
+    // thirteen steps instead of seventeen --; from 8192 points on 18 is still best: profiles/r04/flow_window_sweep.txt)
+    if (C::F::DEG == 1) pc = pick_precomp_bits(n, 8.0, n <= 4096 ? 14 : 18);
     else if (C::F::DEG == 2) pc = pick_precomp_bits(n, 8.0, n >= ((size_t)1 << 16) ? 18 : 2);
     else pc = (n <= ((size_t)1 << 15) && !getenv("MNT753_MSM_PRE_C")) ? 14 : pick_precomp_bits(n, 8.0, 2);
     pW = (754 + pc - 1) / pc;
@@ -579,6 +581,12 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
   }
 }
 
+// one addition per group of lanes in the launches that are one addition deep (msm_flow.hip.h): on unless MNT753_FLOW=0
+inline bool flow_enabled() {   // (read per call, like the other switches of the merge: the tests flip them inside one process)
+  const char* e = getenv("MNT753_FLOW");
+  return !(e && atoi(e) == 0);
+}
+
 // The stages that run point arithmetic.  V = the configuration the point-operation VM is instantiated with (C itself,
 // or its lane-split counterpart); kernels that only move points are layout-agnostic and use C.
 template <class V, class C>
@@ -605,7 +613,7 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
   HIP_TRY(hipEventRecord(b->ev[2], st));
   // the edge pieces of the buckets that span several lanes: a K-ary tree over the lanes of every bucket (k_edge_tree_level; round 4),
   // or the pointer-jumping merge of rounds 1-3 (MNT753_EDGE_TREE=0)
-  static const bool edge_tree = !(getenv("MNT753_EDGE_TREE") && atoi(getenv("MNT753_EDGE_TREE")) == 0);
+  const bool edge_tree = !(getenv("MNT753_EDGE_TREE") && atoi(getenv("MNT753_EDGE_TREE")) == 0);
   if (edge_tree) {
     const uint32_t n_slots = 2 * acc_lanes;
     const unsigned gs = (n_slots + 255) / 256, gv = blocks_for<typename V::F>(n_slots);
@@ -613,9 +621,32 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
     // (T, lanes) the accumulate kernel ran with: its BLOCKED form takes T2 and derives the real share from the list's actual length
     const uint32_t t_arg = n_pair_levels > 0 ? acc_T : p.T;
     const uint32_t* offs = acc_offs;
-    HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));
+    HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 128, st));
     uint32_t level = 0;
+    // A level is one addition deep.  From the level on that can hold at most MNT753_EDGE_FLOW_NODES additions (estimated as lanes / 2^l:
+    // one node per lane boundary at the first level, half as many per level after it) each addition is spread over a group of lanes
+    // and the nodes come from a list (msm_flow.hip.h: k_edge_nodes, k_edge_tree_level_list); the levels before it run one addition per
+    // lane of the VM over all slots.  MNT753_FLOW=0 turns the lane groups off everywhere.
+    const uint64_t flow_edge_nodes = !flow_enabled() ? 0 : getenv("MNT753_EDGE_FLOW_NODES") ? strtoull(getenv("MNT753_EDGE_FLOW_NODES"), nullptr, 10)
+                                            : (C::F::DEG == 2 ? 8192 : 16384);
+    uint32_t* counts = b->d_edge_flags + 40;               // nodes of level l, behind the 40 flags
+    uint4* lists[2] = {reinterpret_cast<uint4*>(b->d_edge_tmp), reinterpret_cast<uint4*>(b->d_edge_tmp) + acc_lanes};   // the old merge's temporary: 2 x lanes entries fit many times
+    bool listed = false;
+    uint32_t parity = 0;
     for (uint64_t stride = 1; stride < acc_lanes; stride *= EDGE_TREE_K, ++level) {
+      if (listed || acc_lanes / stride <= flow_edge_nodes) {
+        if (!listed) {
+          hipLaunchKernelGGL((k_edge_nodes<C>), dim3(gs), dim3(256), 0, st, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked, (uint32_t)stride, b->d_edge_flags,
+                             level, lists[0], counts + level);
+          listed = true;
+        }
+        // most nodes the level can have: two pieces per lane, a node takes two pieces `stride` apart
+        const uint64_t most = std::min<uint64_t>(acc_lanes, 2 * ((uint64_t)acc_lanes / stride) + 1);
+        hipLaunchKernelGGL((k_edge_tree_level_list<C>), dim3((unsigned)((most + Flow<C>::PER_WAVE - 1) / Flow<C>::PER_WAVE)), dim3(64), 0, st, b->d_edges, offs, p.n_buckets,
+                           t_arg, acc_lanes, blocked, (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
+        parity ^= 1u;
+        continue;
+      }
       if (mask & 2u)
         hipLaunchKernelGGL((k_edge_tree_level<V>), dim3(gv), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked,
                            (uint32_t)stride, b->d_edge_flags, level);
@@ -663,8 +694,17 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
   // bucket reduction: k = c - 1 halving steps (each one group addition deep), then the c points per bucket set for the host
   {
     const uint32_t k = (uint32_t)p.c - 1u, NS = p.n_sets;
+    // the narrowest steps: one group of lanes per addition (four products deep instead of fourteen / eight), up to the number of
+    // additions at which the kernels below, with more additions per wave, catch up (MNT753_REDUCE_FLOW_MAX moves it)
+    const uint64_t flow_max = !flow_enabled() ? 0 : getenv("MNT753_REDUCE_FLOW_MAX") ? strtoull(getenv("MNT753_REDUCE_FLOW_MAX"), nullptr, 10)
+                              : (C::F::DEG == 3 ? 16384 : (C::F::DEG == 2 ? 4096 : 8192));
     for (uint32_t step = 0; step < k; ++step) {
       const uint64_t items = (uint64_t)NS * red_items(k, step);
+      if (items <= flow_max) {
+        hipLaunchKernelGGL((k_reduce_step_flow<C>), dim3((unsigned)((items + Flow<C>::PER_WAVE - 1) / Flow<C>::PER_WAVE)), dim3(64), 0, st, b->d_buckets, b->d_offsets,
+                           b->d_part_a, b->d_part_b, NS, k, step);
+        continue;
+      }
       // narrow steps of a base field: two lanes per addition (8 sequential products instead of 14), MNT753_REDUCE_PAIR=0 turns it off
       static const bool pair_tail = !(getenv("MNT753_REDUCE_PAIR") && atoi(getenv("MNT753_REDUCE_PAIR")) == 0);
       static const uint64_t pair_max = getenv("MNT753_REDUCE_PAIR_MAX") ? strtoull(getenv("MNT753_REDUCE_PAIR_MAX"), nullptr, 10) : 65536;   // lanes

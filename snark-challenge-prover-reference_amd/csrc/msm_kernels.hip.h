@@ -1955,3 +1955,5 @@ __global__ void __launch_bounds__(256, 1) k_precompute_windows(uint32_t* __restr
 }
 
 }  // namespace mnt753
+
+#include "msm_flow.hip.h"

@@ -81,7 +81,8 @@ def _cases(gpu, curve, group):
     return out
 
 
-FORMS = {0: "VM addition", 2: "VM mixed addition", 3: "straight-line mixed addition", 4: "two point-lanes per addition", 5: "straight-line addition"}
+FORMS = {0: "VM addition", 2: "VM mixed addition", 3: "straight-line mixed addition", 4: "two point-lanes per addition", 5: "straight-line addition",
+         6: "one group of lanes per addition"}
 
 
 @pytest.mark.parametrize("curve,group,split", [(0, 1, 0), (1, 1, 0), (0, 2, 0), (0, 2, 1), (1, 2, 0), (1, 2, 1)])
@@ -89,6 +90,8 @@ FORMS = {0: "VM addition", 2: "VM mixed addition", 3: "straight-line mixed addit
 def test_device_group_law_vs_libff_goldens(gpu, curve, group, split, form):
     if form == 4 and group == 2 and not split:
         pytest.skip("the two-lanes addition exists for base fields and the lane-split fields")
+    if form == 6 and split:
+        pytest.skip("the lane-group addition is instantiated with the one-lane configuration (its fallback picks the lane-split one itself)")
     cases = _cases(gpu, curve, group)
     if form in (2, 3):
         cases = [c for c in cases if c[3]]     # mixed additions read Q as an affine point
@@ -125,38 +128,28 @@ def test_device_group_law_ragged_batch_vs_oracle(gpu, curve, group, split):
     want = np.stack([O.point_op(curve, group, 0, a, b) for a, b in zip(A, B)])
     P = np.stack([_proj(gpu, curve, group, a) for a in A]); Q = np.stack([_proj(gpu, curve, group, b) for b in B])
     for form in sorted(FORMS):
-        got = gpu.api.test_point_op(curve, group, split, form, P, Q).reshape(n, -1)
+        got = gpu.api.test_point_op(curve, group, 0 if form == 6 else split, form, P, Q).reshape(n, -1)
         res = np.stack([gpu.point_to_affine(curve, group, g) for g in got])
         assert np.array_equal(res, want), FORMS[form]
 
 
-@pytest.mark.parametrize("curve", [0, 1])
-@pytest.mark.parametrize("group", [1, 2])
-@pytest.mark.parametrize("levels,irr", [(1, 0), (2, 1)])
-def test_affine_pair_addition_of_the_pairing_levels_vs_libff_goldens(gpu, curve, group, levels, irr, monkeypatch):
-    """k_pair_level's affine addition with its kinds (add / double / cancel / single) and sign flags, through two-point MSMs with the
-    window table and the pairing levels forced on and 8-bit windows: scalars (1, 1) put P and Q into bucket 0 of window 0 -- one affine
-    addition, the golden P + Q; (255, 1): Booth digits -1 | +1 of 255 put -P, 2^8 P and Q into that bucket (negated entries); (3, 3):
-    bucket 2; (1, -1): every window, the golden P - Q."""
-    monkeypatch.setenv("MNT753_MSM_PRECOMP", "1")
-    monkeypatch.setenv("MNT753_MSM_PRE_C", "8")
-    monkeypatch.setenv("MNT753_MSM_PAIR", str(levels))
-    monkeypatch.setenv("MNT753_MSM_IRR", str(irr))
-    one = gpu.api.mont_one(curve)
-    minus_one = O.field_op(curve, 5, one)          # Fr of MNT4753 is modulus A (0), of MNT6753 modulus B (1)
-    small = {1: one}
-    for v in range(2, 256):
-        small[v] = O.field_op(curve, 1, small[v - 1], one)
-    for k, r in enumerate(G.groupkat(curve, group)):
-        bs = gpu.BaseSet(curve, group, np.stack([r["P"], r["Q"]]))
-        got = gpu.point_to_affine(curve, group, bs.msm(np.stack([one, one])))
-        plan = gpu.api.msm_last_plan()
-        assert plan["pair_levels"] == levels and plan["window_bits"] == 8 and plan["window_table"]
-        assert np.array_equal(got, r["sum"]), f"record {k}: P + Q"
-        got = gpu.point_to_affine(curve, group, bs.msm(np.stack([one, minus_one])))
-        assert np.array_equal(got, r["diff"]), f"record {k}: P - Q"
-        for s1, s2 in ((255, 1), (3, 3), (255, 255), (128, 127)):
-            got = gpu.point_to_affine(curve, group, bs.msm(np.stack([small[s1], small[s2]])))
-            want = O.point_op(curve, group, 0, O.point_op(curve, group, 3, r["P"], small[s1]), O.point_op(curve, group, 3, r["Q"], small[s2]))
-            assert np.array_equal(got, want), f"record {k}: {s1} P + {s2} Q"
-        bs.close()
+@pytest.mark.parametrize("curve,group", [(0, 1), (1, 1), (0, 2), (1, 2)])
+def test_lane_group_addition_identities_and_coordinates(gpu, curve, group):
+    """The lane-group addition (msm_flow.hip.h) on the cases the golden records do not hold: an identity on either side or both, equal
+    points next to ordinary ones in one wave (the fallback runs on a few lanes of a group while its neighbours are done), a count that
+    leaves groups of the last wave without an addition -- and the same PROJECTIVE coordinates as the VM's addition, not only the same
+    point (both follow operator+ of the reference line by line, so every coordinate agrees mod p)."""
+    n = 37
+    pts = gpu.synth_points(curve, group, 977, 2 * n)
+    A = np.stack([_proj(gpu, curve, group, a) for a in pts[:n]]); B = np.stack([_proj(gpu, curve, group, b) for b in pts[n:]])
+    A = np.stack([gpu.point_add(curve, group, a, a) for a in A])                   # Z != 1 on one side
+    zero = _proj(gpu, curve, group, np.zeros_like(pts[0]))
+    A[3] = zero; B[8] = zero; A[20] = zero; B[20] = zero
+    for i in (0, 1, 2, 17, 36): B[i] = A[i]
+    split = 1 if group == 2 else 0
+    vm = gpu.api.test_point_op(curve, group, split, 0, A, B).reshape(n, -1)
+    flow = gpu.api.test_point_op(curve, group, 0, 6, A, B).reshape(n, -1)
+    for i in range(n):
+        assert np.array_equal(gpu.point_to_affine(curve, group, flow[i]), gpu.point_to_affine(curve, group, vm[i])), i
+    ordinary = [i for i in range(n) if i not in (0, 1, 2, 3, 8, 17, 20, 36)]
+    assert np.array_equal(flow[ordinary], vm[ordinary])      # the hooks return canonical coordinates

@@ -136,6 +136,39 @@ def test_skewed_scalars_large(gpu):
     bs.close()
 
 
+MERGES = {"lane groups from the first level": {"MNT753_EDGE_FLOW_NODES": "100000000"}, "lane groups from the third level": {"MNT753_EDGE_FLOW_NODES": "150"},
+          "one VM addition per lane": {"MNT753_FLOW": "0"}, "pointer jumping": {"MNT753_FLOW": "0", "MNT753_EDGE_TREE": "0"}}
+
+
+@pytest.mark.parametrize("merge", sorted(MERGES))
+@pytest.mark.parametrize("curve,group", GROUPS)
+def test_deep_edge_merge_every_form(gpu, curve, group, merge, monkeypatch):
+    """Buckets that span MANY accumulate lanes (one or two entries per lane, a few hundred entries per bucket: trees eight levels deep
+    with ragged ends), for every form of the edge merge: the tree on lane groups with its node lists (msm_flow.hip.h) from the first
+    level and behind two levels of the VM form, the VM form alone, the pointer-jumping merge of rounds 1-3.  Uniform scalars, a vector
+    that is half ones, all scalars equal, and equal points inside one bucket (a doubling inside the merge).  The inlined VM addition of
+    the first tree kernel returned wrong sums exactly here (deep trees, two of the four groups) while every large test passed."""
+    for k, v in MERGES[merge].items():
+        monkeypatch.setenv(k, v)
+    n = 600
+    pts = gpu.synth_points(curve, group, 7100 + group, n)
+    rnd = gpu.synth_scalars(curve, 7200 + curve, n)
+    one = gpu.api.mont_one(curve)
+    half = rnd.copy(); half[::2] = one
+    same = np.tile(rnd[3], (n, 1))
+    dup = pts.copy(); dup[1::2] = dup[0::2]                       # pairs of equal points ...
+    for t_min in (1, 2):
+        monkeypatch.setenv("MNT753_MSM_TMIN", str(t_min))
+        bs = gpu.BaseSet(curve, group, pts)
+        for sc in (rnd, half, same):
+            sc = np.ascontiguousarray(sc)
+            assert np.array_equal(gpu.point_to_affine(curve, group, bs.msm(sc)), gpu.point_to_affine(curve, group, gpu.synth_expected_msm(curve, group, 7100 + group, sc))), (merge, t_min)
+        bs.close()
+    monkeypatch.setenv("MNT753_MSM_TMIN", "1")
+    sc = np.ascontiguousarray(same[:64])                          # ... with equal scalars: every lane of a bucket holds the same point
+    assert np.array_equal(gpu_msm_affine(gpu, curve, group, dup[:64], sc), O.msm(curve, group, dup[:64], sc)), merge
+
+
 def test_async_start_finish_concurrent_base_sets(gpu):
     """mnt753_msm_start / _finish: several base sets in flight at once (the five MSMs of one proof), results identical
     to the synchronous call; a second start on a busy base set is refused."""

@@ -1,0 +1,66 @@
+#!/bin/bash
+# round 4, GPU call H: the lane-group addition (msm_flow.hip.h): known answers, the MSM suite, timings with and without it, a kernel trace
+mkdir -p gpurun_out/r4h
+export TMPDIR=/tmp
+O=$PWD/gpurun_out/r4h
+R=$PWD
+( time python -m pytest tests/test_device_kat_gpu.py tests/test_msm_gpu.py -m gpu -q ) > $O/pytest.log 2>&1
+echo "pytest rc=$?"; grep -E "^FAILED|passed|failed" $O/pytest.log | cut -c1-150 | head -20
+cat > /tmp/flow.py <<'PY'
+import json, os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np
+from __graft_entry__ import load_package
+pkg = load_package(); pkg.init(0)
+tag = os.environ.get("TAG", "default")
+cases = [(1, 1, 12), (1, 2, 12), (1, 1, 15), (1, 2, 15), (0, 1, 15), (0, 2, 15), (0, 2, 17)]
+if os.environ.get("BIG"): cases += [(0, 1, 20), (0, 2, 20)]
+for curve, group, logn in cases:
+    n = 1 << logn
+    pts = pkg.synth_points(curve, group, 42, n); sc = pkg.synth_scalars(curve, 43, n)
+    bs = pkg.BaseSet(curve, group, pts); d = pkg.DeviceBuffer.from_numpy(sc)
+    best = None
+    for rep in range(6):
+        res = bs.msm(d.ptr.value, n=n, on_device=True); t = pkg.msm_last_timing()
+        if rep and (best is None or t["total_ms"] < best["total_ms"]): best = t
+    want = pkg.synth_expected_msm(curve, group, 42, sc)
+    ok = None
+    if want is not None:
+        ok = bool(np.array_equal(pkg.point_to_affine(curve, group, res), pkg.point_to_affine(curve, group, want)))
+    bs.close(); d.close()
+    print(json.dumps({"flow": tag, "curve": curve, "group": group, "log2_n": logn, "ok": ok, **{k: round(v, 3) for k, v in best.items()}}), flush=True)
+PY
+REPO=$R TAG=on BIG=1 python /tmp/flow.py > $O/flow_on.txt 2>&1; echo "on rc=$?"
+REPO=$R TAG=off BIG=1 MNT753_FLOW=0 python /tmp/flow.py > $O/flow_off.txt 2>&1; echo "off rc=$?"
+paste -d'\n' $O/flow_on.txt $O/flow_off.txt | cut -c1-220
+cat > /tmp/one.py <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["REPO"])
+from __graft_entry__ import load_package
+pkg = load_package(); pkg.init(0)
+n = 1 << 15
+pts = pkg.synth_points(1, 2, 42, n); sc = pkg.synth_scalars(1, 43, n)
+bs = pkg.BaseSet(1, 2, pts); d = pkg.DeviceBuffer.from_numpy(sc)
+for rep in range(4): bs.msm(d.ptr.value, n=n, on_device=True)
+print(pkg.msm_last_timing())
+PY
+cd /tmp
+REPO=$R rocprofv3 --kernel-trace --stats -d $O/kt -o t -- python3 /tmp/one.py > $O/one.log 2>&1
+cd $R
+python3 - <<'PY'
+import sqlite3, glob, os
+O = os.path.join(os.getcwd(), "gpurun_out", "r4h")
+for db in glob.glob(f"{O}/kt/**/*_results.db", recursive=True):
+    con = sqlite3.connect(db); cur = con.cursor()
+    t = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [x for x in t if "kernel_dispatch" in x][0]; ks = [x for x in t if "kernel_symbol" in x][0]
+    rows = list(cur.execute(f"select s.display_name, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
+    # the last MSM: everything after the last k_scalar_digits
+    last = max(i for i, (n, _) in enumerate(rows) if "k_scalar_digits" in n or "k_part" in n.lower() and "hist" in n.lower())
+    with open(f"{O}/mnt6_g2_2p15_last_msm_kernels.txt", "w") as f:
+        for n, dt in rows[last:]:
+            line = f"{dt / 1e3:9.1f} us  {n.split('(')[0][:110]}"
+            f.write(line + "\n")
+    con.close(); os.remove(db)
+print(open(f"{O}/mnt6_g2_2p15_last_msm_kernels.txt").read())
+PY
