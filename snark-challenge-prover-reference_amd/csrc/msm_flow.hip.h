@@ -298,6 +298,19 @@ __global__ void __launch_bounds__(256) k_edge_nodes(const uint32_t* __restrict__
   const uint32_t pos = atomicAdd(count, 1u);
   list[pos] = make_uint4(edge_piece_slot(t_lo + (uint32_t)first, t_lo, o0, T), edge_piece_slot(t_lo + (uint32_t)(first + stride), t_lo, o0, T), b, i);
 }
+// node i of a level (i even) becomes node i / 2 of the next one: same destination, the partner 2 S pieces on -- if the bucket reaches
+// that far.  Called by ONE thread per node, after the node's sum is stored.
+__device__ __forceinline__ void edge_emit_next(const uint4 node, const uint32_t* __restrict__ offsets, uint32_t n_buckets, uint32_t T_arg, uint32_t n_lanes,
+                                               uint32_t blocked, uint32_t stride, uint4* __restrict__ list_out, uint32_t* __restrict__ count_out) {
+  if ((node.w & 1u) != 0u) return;
+  const uint32_t T = acc_entries_per_lane(T_arg, n_lanes, offsets[n_buckets], blocked != 0);
+  const uint32_t o0 = offsets[node.z], o1 = offsets[node.z + 1];
+  const uint32_t t_lo = o0 / T, kk = (o1 - 1u) / T - t_lo + 1u;
+  const uint64_t first = (uint64_t)node.w * stride * 2u, partner = first + 2ull * stride;
+  if (partner >= kk) return;
+  const uint32_t pos = atomicAdd(count_out, 1u);
+  list_out[pos] = make_uint4(node.x, edge_piece_slot(t_lo + (uint32_t)partner, t_lo, o0, T), node.z, node.w >> 1);
+}
 template <class C>
 __global__ void __launch_bounds__(64) k_edge_tree_level_list(uint32_t* __restrict__ edges, const uint32_t* __restrict__ offsets, uint32_t n_buckets, uint32_t T_arg,
                                                             uint32_t n_lanes, uint32_t blocked, uint32_t stride, const uint4* __restrict__ list_in,
@@ -313,15 +326,27 @@ __global__ void __launch_bounds__(64) k_edge_tree_level_list(uint32_t* __restric
   const uint4 node = act ? list_in[item] : make_uint4(0u, 0u, 0u, 1u);
   constexpr int PW = proj_words<C>();
   flow_add<C>(lds + gi * FL::GROUP_WORDS, l, edges + (size_t)node.x * PW, edges + (size_t)node.y * PW, false, false, edges + (size_t)node.x * PW, act);
-  if (!act || l != 0u || (node.w & 1u) != 0u) return;
-  // node i / 2 of the next level: this node's sum and the one 2 S pieces on, if the bucket reaches that far
-  const uint32_t T = acc_entries_per_lane(T_arg, n_lanes, offsets[n_buckets], blocked != 0);
-  const uint32_t o0 = offsets[node.z], o1 = offsets[node.z + 1];
-  const uint32_t t_lo = o0 / T, kk = (o1 - 1u) / T - t_lo + 1u;
-  const uint64_t first = (uint64_t)node.w * stride * 2u, partner = first + 2ull * stride;
-  if (partner >= kk) return;
-  const uint32_t pos = atomicAdd(count_out, 1u);
-  list_out[pos] = make_uint4(node.x, edge_piece_slot(t_lo + (uint32_t)partner, t_lo, o0, T), node.z, node.w >> 1);
+  if (!act || l != 0u) return;
+  edge_emit_next(node, offsets, n_buckets, T_arg, n_lanes, blocked, stride, list_out, count_out);
+}
+// The same level with one VM addition per (logical) lane, for the levels that hold too many nodes for the lane groups to win: dense
+// waves over the list instead of one node in two slots (the slot-driven k_edge_tree_level: 2048 half-empty waves for 65536 lanes).
+template <class C>
+__global__ void __launch_bounds__(256, vm_waves<C>()) k_edge_tree_level_vmlist(uint32_t* __restrict__ edges, const uint32_t* __restrict__ offsets, uint32_t n_buckets,
+                                                                  uint32_t T_arg, uint32_t n_lanes, uint32_t blocked, uint32_t stride,
+                                                                  const uint4* __restrict__ list_in, const uint32_t* __restrict__ count_in,
+                                                                  uint4* __restrict__ list_out, uint32_t* __restrict__ count_out) {
+  const uint32_t j = logical_lane<typename C::F>();     // 0xffffffff for the idle 64th lane of three-lane fields
+  if (j >= *count_in) return;
+  const uint4 node = list_in[j];
+  Proj<C> acc, Q;
+  proj_load<C>(acc, edges + (size_t)node.x * proj_words<C>());
+  proj_load<C>(Q, edges + (size_t)node.y * proj_words<C>());
+  const int pc = add_pc<C>(acc, Q);
+  pt_vm_add_outlined<C>(acc, Q, pc);
+  proj_store<C>(edges + (size_t)node.x * proj_words<C>(), acc);
+  if (lane_comp<typename C::F>() != 0u) return;
+  edge_emit_next(node, offsets, n_buckets, T_arg, n_lanes, blocked, stride, list_out, count_out);
 }
 
 // a list of independent additions out[i] = p[i] + q[i] (points in the device layout): the test hook's view of flow_add

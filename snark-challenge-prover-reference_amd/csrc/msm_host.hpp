@@ -623,27 +623,30 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
     const uint32_t* offs = acc_offs;
     HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 128, st));
     uint32_t level = 0;
-    // A level is one addition deep.  From the level on that can hold at most MNT753_EDGE_FLOW_NODES additions (estimated as lanes / 2^l:
-    // one node per lane boundary at the first level, half as many per level after it) each addition is spread over a group of lanes
-    // and the nodes come from a list (msm_flow.hip.h: k_edge_nodes, k_edge_tree_level_list); the levels before it run one addition per
-    // lane of the VM over all slots.  MNT753_FLOW=0 turns the lane groups off everywhere.
-    const uint64_t flow_edge_nodes = !flow_enabled() ? 0 : getenv("MNT753_EDGE_FLOW_NODES") ? strtoull(getenv("MNT753_EDGE_FLOW_NODES"), nullptr, 10)
-                                            : (C::F::DEG == 2 ? 8192 : 16384);
+    // A level is one addition deep, and its nodes are a LIST (msm_flow.hip.h): k_edge_nodes writes the first one, every level appends
+    // the nodes of the next as its last act, launches are sized for the most nodes the level can have.  A level that can hold at most
+    // MNT753_EDGE_FLOW_NODES additions (default 32768 for the base fields, 16384 for Fq2 / Fq3; estimated as lanes / 2^l: one node
+    // per lane boundary at the first level, half as many per level after it) spreads each addition over a group of lanes, the levels
+    // before it run one VM addition per lane over the list.  MNT753_FLOW=0: the slot-driven levels of the first tree (no lists).
+    const uint64_t flow_edge_nodes = getenv("MNT753_EDGE_FLOW_NODES") ? strtoull(getenv("MNT753_EDGE_FLOW_NODES"), nullptr, 10) : (C::F::DEG == 1 ? 32768 : 16384);
     uint32_t* counts = b->d_edge_flags + 40;               // nodes of level l, behind the 40 flags
     uint4* lists[2] = {reinterpret_cast<uint4*>(b->d_edge_tmp), reinterpret_cast<uint4*>(b->d_edge_tmp) + acc_lanes};   // the old merge's temporary: 2 x lanes entries fit many times
-    bool listed = false;
     uint32_t parity = 0;
+    if (flow_enabled() && acc_lanes > 1)
+      hipLaunchKernelGGL((k_edge_nodes<C>), dim3(gs), dim3(256), 0, st, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked, 1u, b->d_edge_flags, 0u, lists[0], counts);
     for (uint64_t stride = 1; stride < acc_lanes; stride *= EDGE_TREE_K, ++level) {
-      if (listed || acc_lanes / stride <= flow_edge_nodes) {
-        if (!listed) {
-          hipLaunchKernelGGL((k_edge_nodes<C>), dim3(gs), dim3(256), 0, st, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked, (uint32_t)stride, b->d_edge_flags,
-                             level, lists[0], counts + level);
-          listed = true;
-        }
+      if (flow_enabled()) {
         // most nodes the level can have: two pieces per lane, a node takes two pieces `stride` apart
         const uint64_t most = std::min<uint64_t>(acc_lanes, 2 * ((uint64_t)acc_lanes / stride) + 1);
-        hipLaunchKernelGGL((k_edge_tree_level_list<C>), dim3((unsigned)((most + Flow<C>::PER_WAVE - 1) / Flow<C>::PER_WAVE)), dim3(64), 0, st, b->d_edges, offs, p.n_buckets,
-                           t_arg, acc_lanes, blocked, (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
+        if (acc_lanes / stride <= flow_edge_nodes)
+          hipLaunchKernelGGL((k_edge_tree_level_list<C>), dim3((unsigned)((most + Flow<C>::PER_WAVE - 1) / Flow<C>::PER_WAVE)), dim3(64), 0, st, b->d_edges, offs, p.n_buckets,
+                             t_arg, acc_lanes, blocked, (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
+        else if (mask & 2u)
+          hipLaunchKernelGGL((k_edge_tree_level_vmlist<V>), dim3(blocks_for<typename V::F>(most)), dim3(256), 0, st, b->d_edges, offs, p.n_buckets, t_arg, acc_lanes, blocked,
+                             (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
+        else
+          hipLaunchKernelGGL((k_edge_tree_level_vmlist<C>), dim3(blocks_for<typename C::F>(most)), dim3(256), 0, st, b->d_edges, offs, p.n_buckets, t_arg, acc_lanes, blocked,
+                             (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
         parity ^= 1u;
         continue;
       }
@@ -788,7 +791,9 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   } else {
     HIP_TRY(hipMemsetAsync(b->d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
     const unsigned gb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_rank, b->d_hist, n, p.c, p.W, p.pre ? 0u : p.nb);
+    // fewer than ~1024 workgroups: the walk over the windows is split (k_scalar_digits), up to eight ways
+    const unsigned wsplit = gb >= 1024 ? 1u : std::min<unsigned>(8u, std::min<unsigned>((unsigned)p.W, (1024u + gb - 1) / gb));
+    hipLaunchKernelGGL((k_scalar_digits<C::FR>), dim3(gb, wsplit), dim3(256), 0, st, d_scal, d_inf, b->d_digits, b->d_rank, b->d_hist, n, p.c, p.W, p.pre ? 0u : p.nb);
     const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);
     // with pairing levels the offsets count groups of 2^levels entries and the padding of the sorted list is ENTRY_EMPTY
     const uint32_t pshift = (uint32_t)p.pair_levels;
@@ -797,7 +802,7 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, b->d_blocksums, (size_t)nsb, b->d_total);
     hipLaunchKernelGGL(k_scan_finish, dim3(nsb), dim3(SCAN_THREADS), 0, st, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total,
                        (size_t)p.n_buckets);
-    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, b->d_digits, b->d_rank, b->d_offsets, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
+    hipLaunchKernelGGL(k_scatter, dim3(gb, wsplit), dim3(256), 0, st, b->d_digits, b->d_rank, b->d_offsets, b->d_sorted, n, p.c, p.W, p.pre ? 0u : p.nb,
                        p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u, pshift);
   }
   HIP_TRY(hipEventRecord(b->ev[1], st));

@@ -137,7 +137,8 @@ def test_skewed_scalars_large(gpu):
 
 
 MERGES = {"lane groups from the first level": {"MNT753_EDGE_FLOW_NODES": "100000000"}, "lane groups from the third level": {"MNT753_EDGE_FLOW_NODES": "150"},
-          "one VM addition per lane": {"MNT753_FLOW": "0"}, "pointer jumping": {"MNT753_FLOW": "0", "MNT753_EDGE_TREE": "0"}}
+          "one VM addition per node of the list": {"MNT753_EDGE_FLOW_NODES": "0"}, "one VM addition per lane over all slots": {"MNT753_FLOW": "0"},
+          "pointer jumping": {"MNT753_FLOW": "0", "MNT753_EDGE_TREE": "0"}}
 
 
 @pytest.mark.parametrize("merge", sorted(MERGES))
@@ -145,7 +146,8 @@ MERGES = {"lane groups from the first level": {"MNT753_EDGE_FLOW_NODES": "100000
 def test_deep_edge_merge_every_form(gpu, curve, group, merge, monkeypatch):
     """Buckets that span MANY accumulate lanes (one or two entries per lane, a few hundred entries per bucket: trees eight levels deep
     with ragged ends), for every form of the edge merge: the tree on lane groups with its node lists (msm_flow.hip.h) from the first
-    level and behind two levels of the VM form, the VM form alone, the pointer-jumping merge of rounds 1-3.  Uniform scalars, a vector
+    level and behind two list-driven levels of the VM form, the VM form alone (from lists, and slot-driven as first built), the
+    pointer-jumping merge of rounds 1-3.  Uniform scalars, a vector
     that is half ones, all scalars equal, and equal points inside one bucket (a doubling inside the merge).  The inlined VM addition of
     the first tree kernel returned wrong sums exactly here (deep trees, two of the four groups) while every large test passed."""
     for k, v in MERGES[merge].items():
