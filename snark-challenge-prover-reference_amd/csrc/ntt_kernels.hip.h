@@ -80,10 +80,14 @@ __global__ void __launch_bounds__(NTT_BLOCK) k_ntt_group(const uint32_t* src, ui
       const size_t j = ((size_t)(e_lo & ((1 << q) - 1)) << s0) + lo;
       const size_t tw_idx = j << (logm - 1 - (s0 + q));
       Fp<M> w, xl, xh, t;
-      fp_load(w, tw + tw_idx * FPS_WORDS);
       lds_load_fp(xl, my + e_lo * FPS_WORDS);
       lds_load_fp(xh, my + e_hi * FPS_WORDS);
-      fp_mul(t, w, xh);
+      if (s0 + q == 0) {
+        t = xh;                                        // the first stage's only twiddle is omega^0 (block-uniform: one product in twenty saved)
+      } else {
+        fp_load(w, tw + tw_idx * FPS_WORDS);
+        fp_mul(t, w, xh);
+      }
       fp_sub(xh, xl, t);
       fp_add(xl, xl, t);
       lds_store_fp(my + e_lo * FPS_WORDS, xl);
