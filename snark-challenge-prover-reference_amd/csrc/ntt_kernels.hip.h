@@ -21,6 +21,9 @@
 
 namespace mnt753 {
 
+#ifndef MNT753_NTT_LAZY
+#define MNT753_NTT_LAZY 1
+#endif
 constexpr int NTT_MAX_NS = 8;                 // stages per LDS group
 constexpr int NTT_BLOCK = 256;                // threads per block = 512 elements per block
 constexpr int NTT_LDS_WORDS = 2 * NTT_BLOCK * FPS_WORDS;
@@ -72,24 +75,50 @@ __global__ void __launch_bounds__(NTT_BLOCK) k_ntt_group(const uint32_t* src, ui
     }
   }
   __syncthreads();
+  // the twiddle of a stage is fetched one stage ahead (its address needs nothing the stage computes): the load's latency then
+  // hides behind a product instead of standing between the barrier and the product
+  auto twiddle_index = [=](int q) -> size_t {
+    const int e_lo = ((bt >> q) << (q + 1)) | (bt & ((1 << q) - 1));
+    const size_t j = ((size_t)(e_lo & ((1 << q) - 1)) << s0) + lo;
+    return j << (logm - 1 - (s0 + q));
+  };
+  Fp<M> w, w_next;
+  fp_zero(w_next);
+  if (active && s0 != 0) fp_load(w_next, tw + twiddle_index(0) * FPS_WORDS);
 #pragma unroll 1
   for (int q = 0; q < ns; ++q) {
     if (active) {
       const int e_lo = ((bt >> q) << (q + 1)) | (bt & ((1 << q) - 1));
       const int e_hi = e_lo + (1 << q);
-      const size_t j = ((size_t)(e_lo & ((1 << q) - 1)) << s0) + lo;
-      const size_t tw_idx = j << (logm - 1 - (s0 + q));
-      Fp<M> w, xl, xh, t;
+      Fp<M> xl, xh, t;
+      w = w_next;
+      if (q + 1 < ns) fp_load(w_next, tw + twiddle_index(q + 1) * FPS_WORDS);
       lds_load_fp(xl, my + e_lo * FPS_WORDS);
       lds_load_fp(xh, my + e_hi * FPS_WORDS);
+#if MNT753_NTT_LAZY
+      // Carry-free butterflies (the lazy arithmetic of the pairing levels, fp753.hip.h): x_lo +- w x_hi limb-wise with signed limbs
+      // (54 instructions instead of the 540 of fp_add + fp_sub), the product through the signed multiplier, and one normalisation
+      // per element every SECOND stage.  Ranges: stage A takes values in [0, 1.51p) with limbs below 2^28 (fresh from fp_unpack or
+      // fp_norm) and a twiddle in [0, 2p): t in (-0.34p, 1.34p), outputs in (-0.85p, 2.85p) with |limb| < 2^29; stage B takes those:
+      // t in (-0.63p, 1.63p), outputs in (-2.48p, 4.48p) with |limb| < 2^29.6 -- inside what fp_norm accepts (|value| < 5p,
+      // |limb| < 2^30), which returns them to [0.49p, 1.51p).  Values mod p are those of the eager form.
       if (s0 + q == 0) {
         t = xh;                                        // the first stage's only twiddle is omega^0 (block-uniform: one product in twenty saved)
       } else {
-        fp_load(w, tw + tw_idx * FPS_WORDS);
+        fp_mul_s(t, w, xh);
+      }
+      fp_sub_raw(xh, xl, t);
+      fp_addsub_raw(xl, xl, t, false);
+      if ((q & 1) || q == ns - 1) { fp_norm(xl, xl); fp_norm(xh, xh); }
+#else
+      if (s0 + q == 0) {
+        t = xh;
+      } else {
         fp_mul(t, w, xh);
       }
       fp_sub(xh, xl, t);
       fp_add(xl, xl, t);
+#endif
       lds_store_fp(my + e_lo * FPS_WORDS, xl);
       lds_store_fp(my + e_hi * FPS_WORDS, xh);
     }
