@@ -82,8 +82,9 @@ int build_tables(mnt753_domain* d) {
 }
 
 // bit-reversal + log2 m butterfly stages, in place on `vec` (via the domain's work buffer)
+// in_scale / out_scale: tables the elements are multiplied by on the way into the first group / out of the last (k_ntt_group)
 template <int M>
-int run_stages(mnt753_domain* d, uint32_t* vec, const uint32_t* tw, hipStream_t st) {
+int run_stages(mnt753_domain* d, uint32_t* vec, const uint32_t* tw, hipStream_t st, const uint32_t* in_scale = nullptr, const uint32_t* out_scale = nullptr) {
   const int logm = d->logm;
   if (logm == 0) return 0;
   int n_groups = (logm + NTT_MAX_NS - 1) / NTT_MAX_NS;
@@ -95,7 +96,8 @@ int run_stages(mnt753_domain* d, uint32_t* vec, const uint32_t* tw, hipStream_t 
     const size_t n_tiles = (size_t)1 << (logm - ns);
     const int tiles_per_block = NTT_BLOCK / (1 << (ns - 1));
     const unsigned blocks = (unsigned)((n_tiles + tiles_per_block - 1) / tiles_per_block);
-    hipLaunchKernelGGL((k_ntt_group<M>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, gi == 0 ? 1 : 0);
+    hipLaunchKernelGGL((k_ntt_group<M>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, gi == 0 ? 1 : 0, gi == 0 ? in_scale : nullptr,
+                       gi == n_groups - 1 ? out_scale : nullptr);
     s0 += ns;
   }
   if (n_groups == 1) HIP_TRY(hipMemcpyAsync(vec, d->work, d->m * 96, hipMemcpyDeviceToDevice, st));
@@ -115,12 +117,9 @@ int fft_t(mnt753_domain* d, int kind, uint32_t* vec, hipStream_t st) {
       hipLaunchKernelGGL((k_vec_mul_const<M>), dim3(gb), dim3(256), 0, st, vec, d->consts, m);
       break;
     case MNT753_COSET_FFT:
-      hipLaunchKernelGGL((k_vec_mul_table<M>), dim3(gb), dim3(256), 0, st, vec, d->cos_fwd, m);
-      return run_stages<M>(d, vec, d->tw_fwd, st);
+      return run_stages<M>(d, vec, d->tw_fwd, st, d->cos_fwd, nullptr);
     case MNT753_ICOSET_FFT:
-      if (int rc = run_stages<M>(d, vec, d->tw_inv, st)) return rc;
-      hipLaunchKernelGGL((k_vec_mul_table<M>), dim3(gb), dim3(256), 0, st, vec, d->cos_inv_s, m);
-      break;
+      return run_stages<M>(d, vec, d->tw_inv, st, nullptr, d->cos_inv_s);
     default:
       return set_error(MNT753_EINVAL, "fft: unknown kind");
   }
@@ -134,11 +133,8 @@ int fft_t(mnt753_domain* d, int kind, uint32_t* vec, hipStream_t st) {
 // x -> cosetFFT(iFFT(x)) = stages(inv), *(g^i/m), stages(fwd)
 template <int M>
 int h_chain_t(mnt753_domain* d, uint32_t* vec, hipStream_t st) {
-  const size_t m = d->m;
-  const unsigned gb = (unsigned)((m + 255) / 256);
   if (int rc = run_stages<M>(d, vec, d->tw_inv, st)) return rc;
-  hipLaunchKernelGGL((k_vec_mul_table<M>), dim3(gb), dim3(256), 0, st, vec, d->cos_fwd_s, m);
-  return run_stages<M>(d, vec, d->tw_fwd, st);
+  return run_stages<M>(d, vec, d->tw_fwd, st, d->cos_fwd_s, nullptr);      // (g^i / m) rides on the forward transform's first pass
 }
 // a = (a*b - c)/Z ; a = icosetFFT(a) ; h = a | 0
 template <int M>
@@ -146,8 +142,7 @@ int h_finish_t(mnt753_domain* d, uint32_t* ca, const uint32_t* cb, const uint32_
   const size_t m = d->m;
   const unsigned gb = (unsigned)((m + 255) / 256);
   hipLaunchKernelGGL((k_h_pointwise<M>), dim3(gb), dim3(256), 0, st, ca, cb, cc, d->consts + 1 * FPS_WORDS, d->consts + 2 * FPS_WORDS, m);
-  if (int rc = run_stages<M>(d, ca, d->tw_inv, st)) return rc;
-  hipLaunchKernelGGL((k_vec_mul_table<M>), dim3(gb), dim3(256), 0, st, ca, d->cos_inv_s, m);
+  if (int rc = run_stages<M>(d, ca, d->tw_inv, st, nullptr, d->cos_inv_s)) return rc;
   const size_t quads = m * 6 + 6;
   hipLaunchKernelGGL(k_copy_h, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, h, ca, m);
   HIP_TRY(hipGetLastError());

@@ -48,9 +48,14 @@ __device__ __forceinline__ void lds_store_fp(uint32_t* p, const Fp<M>& a) {
 
 // stages [s0, s0 + ns) of the decimation-in-time transform of size 2^logm.
 //   src/dst: wire vectors (may alias unless bitrev is set);  tw: omega^i, i < m/2, device form.
+//   in_scale / out_scale (may be null): tables in device form the elements are multiplied by as they are read (index = the element's
+//   position in `src`) / written (position in `dst`) -- libfqfft's coset and 1/m loops ride on the transform's own passes over HBM
+//   instead of a pass of their own (k_vec_mul_table: 0.10 ms per 2^20 elements, four of them in compute_H).  A product of a canonical
+//   element and a table entry below 2p is below 1.22p, inside the range the first carry-free stage assumes.
 template <int M>
 __global__ void __launch_bounds__(NTT_BLOCK) k_ntt_group(const uint32_t* src, uint32_t* dst,
-                                                        const uint32_t* __restrict__ tw, int logm, int s0, int ns, int bitrev) {
+                                                        const uint32_t* __restrict__ tw, int logm, int s0, int ns, int bitrev,
+                                                        const uint32_t* __restrict__ in_scale, const uint32_t* __restrict__ out_scale) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[NTT_LDS_WORDS];
   const int tpt = 1 << (ns - 1);                       // threads (= butterflies) per tile
   const int tiles_per_block = NTT_BLOCK / tpt;
@@ -71,6 +76,12 @@ __global__ void __launch_bounds__(NTT_BLOCK) k_ntt_group(const uint32_t* src, ui
       load_wire24(w, src + idx * 24);
       Fp<M> x;
       fp_unpack(x, w);
+      if (in_scale) {
+        Fp<M> k, y;
+        fp_load(k, in_scale + idx * FPS_WORDS);
+        fp_mul(y, x, k);
+        x = y;
+      }
       lds_store_fp(my + e * FPS_WORDS, x);
     }
   }
@@ -131,6 +142,12 @@ __global__ void __launch_bounds__(NTT_BLOCK) k_ntt_group(const uint32_t* src, ui
       const size_t idx = base_idx + ((size_t)e << s0);
       Fp<M> x, c;
       lds_load_fp(x, my + e * FPS_WORDS);
+      if (out_scale) {
+        Fp<M> k, y;
+        fp_load(k, out_scale + idx * FPS_WORDS);
+        fp_mul(y, x, k);
+        x = y;
+      }
       fp_canon(c, x);
       uint32_t w[24];
       fp_pack(w, c);
