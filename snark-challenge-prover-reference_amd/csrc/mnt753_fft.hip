@@ -96,8 +96,13 @@ int run_stages(mnt753_domain* d, uint32_t* vec, const uint32_t* tw, hipStream_t 
     const size_t n_tiles = (size_t)1 << (logm - ns);
     const int tiles_per_block = NTT_BLOCK / (1 << (ns - 1));
     const unsigned blocks = (unsigned)((n_tiles + tiles_per_block - 1) / tiles_per_block);
-    hipLaunchKernelGGL((k_ntt_group<M>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, gi == 0 ? 1 : 0, gi == 0 ? in_scale : nullptr,
-                       gi == n_groups - 1 ? out_scale : nullptr);
+    const uint32_t* is = gi == 0 ? in_scale : nullptr;
+    const uint32_t* os = gi == n_groups - 1 ? out_scale : nullptr;
+    const int bitrev = gi == 0 ? 1 : 0;
+    if (is && os) hipLaunchKernelGGL((k_ntt_group<M, true, true>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, bitrev, is, os);
+    else if (is) hipLaunchKernelGGL((k_ntt_group<M, true, false>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, bitrev, is, os);
+    else if (os) hipLaunchKernelGGL((k_ntt_group<M, false, true>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, bitrev, is, os);
+    else hipLaunchKernelGGL((k_ntt_group<M, false, false>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, bitrev, is, os);
     s0 += ns;
   }
   if (n_groups == 1) HIP_TRY(hipMemcpyAsync(vec, d->work, d->m * 96, hipMemcpyDeviceToDevice, st));
