@@ -1,5 +1,6 @@
 // The MSM part of the C ABI (include/mnt753_hip.h): dispatch to the per-group instantiations.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include "common_host.hpp"
@@ -20,10 +21,14 @@ namespace {
 // MSM streams run at the lowest priority the device offers: an MSM is hundreds of milliseconds of throughput work,
 // and short kernels on the default stream (the NTTs of compute_H, launched while MSMs are in flight) should be
 // scheduled ahead of its remaining workgroups.
-hipError_t create_msm_stream(hipStream_t* s) {
+// (MNT753_G2_STREAM_PRIO=1, development: the G2 sets one level above the G1 ones, so that the longest MSM of a prove gets the wave
+// slots first and its latency-bound tail runs under the others' throughput phases)
+hipError_t create_msm_stream(hipStream_t* s, int group) {
   int least = 0, greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
-  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; greatest = 0; }
+  int prio = least;
+  if (group == MNT753_G2 && greatest < least && getenv("MNT753_G2_STREAM_PRIO") && atoi(getenv("MNT753_G2_STREAM_PRIO")) != 0) prio = least - 1;
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
 }
 }  // namespace
 
@@ -42,7 +47,7 @@ int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_dev
   else rc = group == MNT753_G1 ? bases_create_mnt6g1(b, affine, on_device, n) : bases_create_mnt6g2(b, affine, on_device, n);
   if (rc) { mnt753_bases_free(b); return rc; }
   // the base set's own stream for mnt753_msm_start (creating a stream costs ~8 ms: do it here, at parameter-load time)
-  if (create_msm_stream(&b->own_stream) != hipSuccess) b->own_stream = nullptr;
+  if (create_msm_stream(&b->own_stream, group) != hipSuccess) b->own_stream = nullptr;
   if (hipEventCreateWithFlags(&b->ev_dep, hipEventDisableTiming) != hipSuccess) b->ev_dep = nullptr;
   (void)hipGetLastError();
   *out = b;
@@ -88,7 +93,7 @@ int mnt753_msm_start(mnt753_bases* b, size_t base_offset, const uint64_t* scalar
   hipStream_t st = (hipStream_t)stream;
   if (!st) {
     // the base set's own non-blocking stream, ordered after everything already enqueued on the default stream
-    if (!b->own_stream) HIP_TRY(create_msm_stream(&b->own_stream));
+    if (!b->own_stream) HIP_TRY(create_msm_stream(&b->own_stream, b->group));
     if (!b->ev_dep) HIP_TRY(hipEventCreateWithFlags(&b->ev_dep, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->ev_dep, nullptr));
     HIP_TRY(hipStreamWaitEvent(b->own_stream, b->ev_dep, 0));

@@ -145,10 +145,10 @@ void prove_one(typename B::groth16_params* params, const char* input_path, const
   B::groth16_output_write(evaluation_At, evaluation_Bt2, C, output_path);
   auto t_out = clk::now();
   if (!g_quiet) {
-    printf("G2 MSM enqueued + compute_H (input streaming in): %.3fs\nremaining MSM time: %.3fs\nC = Ht + Lt + r*Bt1: %.3fs%s\ngpu: %.3fs\nstore: %.3fs\n", secs(t_in, t_h), secs(t_h, t_msm),
+    printf("G2 MSM enqueued + compute_H (input streaming in): %.3fs\nremaining MSM time: %.3fs\nC = Ht + Lt + r*Bt1: %.3fs%s\ngpu: %.4fs\nstore: %.3fs\n", secs(t_in, t_h), secs(t_h, t_msm),
            secs(t_msm, t_c), g_fused_c ? " (one MSM over H | L | B1)" : "", secs(t_in, t_c), secs(t_c, t_out));
     printf("input file on the device after: %.3fs (background loader)\n", B::input_load_seconds(input));
-    printf("Total time from input to output: %.3fs\n", secs(t_main, t_out));
+    printf("Total time from input to output: %.4fs\n", secs(t_main, t_out));
     if (first) printf("Total wall (incl. load params): %.3fs\n", secs(t0, t_out));
   }
 
