@@ -125,6 +125,15 @@ int mnt753_msm(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int
  * MSM may be in flight per base set. */
 int mnt753_msm_start(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n, void* stream);
 int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective);
+/* Order the throughput phases of two MSMs that are in flight together: the point kernels (pairing levels, accumulate: the ones that
+ * fill the chip) of b's NEXT mnt753_msm_start begin when those of `first`'s latest mnt753_msm_start have ended; b's sort still runs
+ * as early as it can.  Without it the two interleave, finish together, and both latency-bound tails (edge merge, bucket reduction:
+ * 1.3 - 3 ms of a 2^20-point MSM during which the chip idles) end the prove; with it first's tail runs under b's point kernels and
+ * only b's is left -- so the MSM with the shortest tail goes last (A behind C in the prove: cuda_prover_piecewise.cu:71-81 starts
+ * them in an order that does not matter there).  Worth it for the small sets (MNT6753 2^15: 15.7 -> 15.2 ms per proof); two
+ * 2^20-point MSMs gain more from filling each other's kernel ends interleaved (measured 157.2 -> 158.4 ms ordered), so the wrapper
+ * orders only below 2^18 points.  Both sets on one device; call it after first's mnt753_msm_start. */
+int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first);
 
 /* window size override (0 = automatic); returns previous value.  Tuning knob, not part of the reference. */
 int mnt753_msm_set_window_bits(int c);

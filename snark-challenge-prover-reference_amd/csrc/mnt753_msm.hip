@@ -70,6 +70,13 @@ int mnt753_bases_free(mnt753_bases* b) {
 
 size_t mnt753_bases_size(const mnt753_bases* b) { return b ? b->n : 0; }
 
+int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first) {
+  if (!b || !first || b == first) return set_error(MNT753_EINVAL, "msm_order_after: two different base sets");
+  if (b->device != first->device) return set_error(MNT753_EINVAL, "msm_order_after: the two base sets live on different devices");
+  b->after_ev = first->ev[2];   // recorded behind the accumulate kernel of first's latest mnt753_msm_start (null before its first: no wait)
+  return 0;
+}
+
 int mnt753_msm(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, int scalars_on_device, size_t n,
                uint64_t* out_projective, void* stream) {
   if (!b || !out_projective || (n && !scalars)) return set_error(MNT753_EINVAL, "msm: null argument");

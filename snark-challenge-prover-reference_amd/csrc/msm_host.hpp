@@ -806,6 +806,8 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
                        p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u, pshift);
   }
   HIP_TRY(hipEventRecord(b->ev[1], st));
+  // mnt753_msm_order_after: the sort above ran whenever it could; the kernels that fill the chip start once the other set's have ended
+  if (b->after_ev) { HIP_TRY(hipStreamWaitEvent(st, b->after_ev, 0)); b->after_ev = nullptr; }
   // point stages: with the lane-split configuration of the group (Fq2: two lanes per point, Fq3: three) when it has
   // one, otherwise one lane per point.  MNT753_MSM_ACC=vm forces one lane.
   uint32_t* cur = nullptr;

@@ -57,5 +57,6 @@ struct mnt753_bases {
   size_t pending_n = 0;
   hipStream_t pending_stream = nullptr, own_stream = nullptr;
   hipEvent_t ev_dep = nullptr;
+  hipEvent_t after_ev = nullptr;   // mnt753_msm_order_after: the point kernels of the next MSM wait for this event (another set's accumulate)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };

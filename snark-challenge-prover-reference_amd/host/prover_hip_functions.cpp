@@ -99,9 +99,15 @@ struct Ready {
     if (!error.empty()) throw std::runtime_error(error);
   }
 };
+// g_gate[g] = the base set of C's MSM on device g until the next MSM there is ordered behind it (start_sharded, below); a base set
+// that is going away is nobody's predecessor any more
+static std::vector<mnt753_bases*> g_gate;
+static void gate_forget(mnt753_bases* b) {
+  for (auto& p : g_gate) if (p == b) p = nullptr;
+}
 struct BaseSetHolder {
   mnt753_bases* h = nullptr;
-  ~BaseSetHolder() { if (h) mnt753_bases_free(h); }
+  ~BaseSetHolder() { if (h) { gate_forget(h); mnt753_bases_free(h); } }
 };
 static int g_n_devices = 0;   // 0: not chosen yet (init_public_params reads MNT753_GPUS, default 1)
 // Ht + Lt + r Bt1 as ONE multi-scalar multiplication over the concatenated base set H | L | B1 (B::groth16_C).  -1: not chosen yet
@@ -799,7 +805,27 @@ static void compact_in_rank_order(PendingMsm& pm) {
     if (pm.sets[g]) { sets.push_back(pm.sets[g]); pm.devs.push_back((int)g); }
   pm.sets.swap(sets);
 }
-static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarSource& src, size_t length, const char* what) {
+// The MSM for C (three times the points of A's) is started first and has the longer latency-bound tail; the next MSM started on a
+// device is ordered behind C's point kernels there (mnt753_msm_order_after): C's tail then runs under that MSM's point kernels instead
+// of ending the prove beside it (g_gate, above).
+// Measured (profiles/r04/prove_msm_order.txt, alternating on one box): MNT6753 2^15 15.7 -> 15.2 ms; MNT4753 2^20 157.2 -> 158.4 ms
+// -- there the two MSMs interleaved fill each other's kernel ends, which is worth more than a hidden 3 ms tail -- so only the small
+// sets are ordered (C over at most 2^18 points on the device).  MNT753_ORDER_MSMS=0: never, =2: always.
+static int order_msms() {
+  static const int mode = getenv("MNT753_ORDER_MSMS") ? atoi(getenv("MNT753_ORDER_MSMS")) : 1;
+  return mode;
+}
+static void gate_set(int g, mnt753_bases* c) {
+  if (order_msms() == 0 || (order_msms() == 1 && mnt753_bases_size(c) > ((size_t)1 << 18))) return;
+  if (g_gate.size() <= (size_t)g) g_gate.resize((size_t)g + 1, nullptr);
+  g_gate[(size_t)g] = c;
+}
+static void gate_apply(int g, mnt753_bases* next) {
+  if ((size_t)g >= g_gate.size() || !g_gate[(size_t)g]) return;
+  if (g_gate[(size_t)g] != next) check(mnt753_msm_order_after(next, g_gate[(size_t)g]), "mnt753_msm_order_after");
+  g_gate[(size_t)g] = nullptr;
+}
+static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarSource& src, size_t length, const char* what, bool is_c = false) {
   auto pend = std::make_shared<PendingMsm>();
   const int n_dev = (int)sb.parts.size();
   pend->sets.resize((size_t)n_dev);
@@ -815,7 +841,9 @@ static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarS
       check(mnt753_copy_peer_async(g, part.scalars->ptr, src.home, src.home_ptr() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
       sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
     }
+    if (!is_c) gate_apply(g, part.set->h);
     check(mnt753_msm_start(part.set->h, 0, sc, 1, hi - lo, nullptr), what);
+    if (is_c) gate_set(g, part.set->h);
     pend->sets[(size_t)g] = part.set;
   }
   // rank order for the fold (multiexp.tcc:433-438), whatever the order of enqueueing was
@@ -845,7 +873,7 @@ static std::shared_ptr<PendingMsm> start_fused_c(typename HIP_B::groth16_params*
     const uint64_t* wp = resident_on(w, 0, 0, m + 1);
     if (!wp) { fetch_into(w, 0, 0, m + 1, s + 12 * (d + m - 1)); wp = s + 12 * (d + m - 1); }
     check(mnt753_vec_scale(CURVE, s + 12 * (d + m - 1), wp, r, m + 1, nullptr), "mnt753_vec_scale");
-    auto pend = start_sharded(sb, ScalarSource{[s]() { return (const uint64_t*)s; }, 0, nullptr, 0}, n, "mnt753_msm_start(C)");
+    auto pend = start_sharded(sb, ScalarSource{[s]() { return (const uint64_t*)s; }, 0, nullptr, 0}, n, "mnt753_msm_start(C)", true);
     pend->scalars = sc;
     return pend;
   }
@@ -873,6 +901,7 @@ static std::shared_ptr<PendingMsm> start_fused_c(typename HIP_B::groth16_params*
       at += hi - lo;
     }
     check(mnt753_msm_start(part.set->h, 0, s, 1, total, nullptr), "mnt753_msm_start(C)");
+    gate_set(g, part.set->h);
     pend->sets[(size_t)g] = part.set;
   }
   compact_in_rank_order(*pend);
