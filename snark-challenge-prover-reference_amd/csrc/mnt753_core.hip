@@ -82,12 +82,24 @@ int init_one(int logical, int phys) {
         if (ok) memset(d.io.lane[l].buf[k], 0, IoStaging::CHUNK);
       }
     }
-    // first use of a stream creates its hardware queue (milliseconds): one small copy per lane now, not inside the first proof
+    // first use of a stream creates its hardware queue, and the first LARGE copy of a stream whatever a copy of that size needs
+    // (a 4 KB copy did not warm it: with several lanes the first input load of a process took 25-45 ms against 10-15 later): both
+    // buffers of every lane go over once now, from threads of their own as in a load, not inside the first proof
     if (ok) {
       void* scratch = nullptr;
-      if (hipMalloc(&scratch, 4096) == hipSuccess) {
-        for (int l = 0; l < IO_LANES; ++l) (void)hipMemcpyAsync(scratch, d.io.lane[l].buf[0], 4096, hipMemcpyHostToDevice, d.io.lane[l].stream);
-        for (int l = 0; l < IO_LANES; ++l) (void)hipStreamSynchronize(d.io.lane[l].stream);
+      if (hipMalloc(&scratch, IoStaging::CHUNK) == hipSuccess) {
+        std::thread warm[IO_LANES];
+        for (int l = 0; l < IO_LANES; ++l)
+          warm[l] = std::thread([&d, l, phys, scratch]() {
+            if (hipSetDevice(phys) != hipSuccess) return;
+            for (int k = 0; k < 2; ++k) {
+              (void)hipMemcpyAsync(scratch, d.io.lane[l].buf[k], IoStaging::CHUNK, hipMemcpyHostToDevice, d.io.lane[l].stream);
+              (void)hipEventRecord(d.io.lane[l].done[k], d.io.lane[l].stream);
+            }
+            (void)hipEventSynchronize(d.io.lane[l].done[1]);
+            (void)hipStreamSynchronize(d.io.lane[l].stream);
+          });
+        for (int l = 0; l < IO_LANES; ++l) warm[l].join();
         (void)hipFree(scratch);
       }
       (void)hipGetLastError();
@@ -340,11 +352,12 @@ int mnt753_load_file_to_device(const char* path, size_t file_offset, size_t byte
     return rc;
   };
   // small reads stay on one lane; large ones are cut into IO_LANES contiguous parts (multiples of CHUNK)
-  // Default ONE lane: what made the loader twice as fast in round 3 was pread straight into the pinned buffer instead of fread through
-  // a stdio buffer (403 MB: 21 -> 12 ms).  More lanes bring a resident prover to 9-10 ms and 0.180 instead of 0.182 s per proof, but
-  // the FIRST proof of a process -- the reference's metric -- pays their thread and queue start-up (0.187-0.195 s), so they are
-  // opt-in (MNT753_IO_LANES=2..4; profiles/r03/prove_io_lanes.txt).
-  static const int max_lanes = [] { const char* e = getenv("MNT753_IO_LANES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > IO_LANES ? IO_LANES : v); }();
+  // What made the loader twice as fast in round 3 was pread straight into the pinned buffer instead of fread through a stdio buffer
+  // (403 MB: 21 -> 12 ms).  More lanes bring the 403 MB of a 2^20 input from 11-17 ms to 10-12; in round 3 the FIRST proof of a
+  // process -- the reference's metric -- paid 5-30 ms for them, which was the first large copy of every lane's stream: the
+  // initialisation sends both buffers of every lane over once since round 4, and two lanes are the default (first proof 0.1562 ->
+  // 0.1557 s median of six alternations, later proofs 0.1552 -> 0.1548: profiles/r04/prove_io_lanes.txt).  MNT753_IO_LANES=1..4.
+  static const int max_lanes = [] { const char* e = getenv("MNT753_IO_LANES"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > IO_LANES ? IO_LANES : v); }();
   const int lanes = bytes >= 4 * CHUNK ? max_lanes : 1;
   const size_t per = ((bytes / (size_t)lanes + CHUNK - 1) / CHUNK) * CHUNK;
   int rcs[IO_LANES] = {0, 0, 0, 0};
