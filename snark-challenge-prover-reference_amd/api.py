@@ -173,6 +173,10 @@ class BaseSet:
         st = C.c_void_p(int(stream)) if stream else C.c_void_p()
         _check(lib().mnt753_msm_start(self._h, base_offset, C.c_void_p(int(scalars_dev_ptr)), 1, int(n), st), "mnt753_msm_start")
 
+    def order_after(self, first):
+        """The point kernels of this set's NEXT msm_start begin when those of `first`'s MSM in flight have ended (mnt753_msm_order_after)."""
+        _check(lib().mnt753_msm_order_after(self._h, first._h), "mnt753_msm_order_after")
+
     def msm_finish(self):
         out = np.zeros(projective_words(self.curve, self.group), dtype=np.uint64)
         _check(lib().mnt753_msm_finish(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_msm_finish")

@@ -194,6 +194,34 @@ def test_async_start_finish_concurrent_base_sets(gpu):
         b.close()
 
 
+def test_msms_ordered_behind_each_other(gpu):
+    """mnt753_msm_order_after: three base sets in flight, the second ordered behind the first's point kernels, the third behind the
+    second's; a chain whose first link never ran an MSM (no event yet: no wait); the order given before and consumed by exactly the
+    next start; results identical to the unordered ones.  Refused: a set behind itself."""
+    n = 5000
+    sc = gpu.synth_scalars(0, 91, n)
+    d = gpu.DeviceBuffer.from_numpy(sc)
+    sets = [(0, 1, 92), (0, 2, 93), (0, 1, 94)]
+    bases = [gpu.BaseSet(c, g, gpu.synth_points(c, g, seed, n)) for c, g, seed in sets]
+    want = [gpu.point_to_affine(c, g, gpu.synth_expected_msm(c, g, seed, sc)) for c, g, seed in sets]
+    with pytest.raises(gpu.Mnt753Error):
+        bases[0].order_after(bases[0])
+    for rnd in range(3):
+        bases[0].msm_start(d.ptr.value, n)
+        bases[1].order_after(bases[0]); bases[1].msm_start(d.ptr.value, n)
+        bases[2].order_after(bases[1]); bases[2].msm_start(d.ptr.value, n)
+        order = (2, 0, 1) if rnd == 1 else (0, 1, 2)
+        got = {}
+        for i in order:
+            got[i] = gpu.point_to_affine(sets[i][0], sets[i][1], bases[i].msm_finish())
+        for i in range(3):
+            assert np.array_equal(got[i], want[i]), (rnd, i)
+    # the order is consumed by one start: the next MSM of the set runs on its own
+    assert np.array_equal(gpu.point_to_affine(0, 2, bases[1].msm(d.ptr.value, n=n, on_device=True)), want[1])
+    for b in bases:
+        b.close()
+
+
 def test_full_size_2pow20_g1_mnt4753(gpu):
     """BASELINE config[1]: 2^20 G1 bases.  Exact check through the discrete logs of the synthetic bases
     (sum_k s_k e_k mod r) * G, plus additivity MSM(s) + MSM(t) == MSM(s + t) as a size-independent property."""
