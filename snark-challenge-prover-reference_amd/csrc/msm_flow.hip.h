@@ -64,16 +64,24 @@ __device__ __forceinline__ FlowTask flow_task(int level, uint32_t m) {
   }
 }
 
+// Fq3 in the Karatsuba form (flow_add_k3 below): 32 lanes per addition, one BASE-field product per lane and round.  Build option
+// -DMNT753_FLOW_K3=0 keeps the fused three-product form on 16 lanes (55 us per addition against ~35).
+#ifndef MNT753_FLOW_K3
+#define MNT753_FLOW_K3 1
+#endif
+enum : uint32_t { FV_A = FV_COUNT, FV_RA, FV_Y3, FVK_COUNT };   // values the Karatsuba form materialises between its rounds
 template <class C>
 struct Flow {
   using F = typename C::F;                            // the ONE-lane field class of the group (FieldFp / FieldFp2 / FieldFp3)
   static_assert(F::LANES == 1, "the flow addition is instantiated with the one-lane configuration; its fallback picks the lane-split one");
   static constexpr int D = F::DEG, M = F::MOD;
-  static constexpr uint32_t G = D == 1 ? 8u : 16u;    // lanes per addition: 5 D products in the widest round
+  static constexpr bool K3 = D == 3 && MNT753_FLOW_K3 != 0;
+  static constexpr uint32_t G = D == 1 ? 8u : (K3 ? 32u : 16u);   // lanes per addition: 5 D products in the widest round (5 x 6 pieces: K3)
   static constexpr uint32_t PER_WAVE = 64u / G;
   static constexpr uint32_t VAL_WORDS = (uint32_t)D * FPS_WORDS;
-  static constexpr uint32_t FLAG_WORDS = 32u;         // [level * 8 + task]: bit 0 the a operand is zero, bit 1 the b operand
-  static constexpr uint32_t GROUP_WORDS = FV_COUNT * VAL_WORDS + FLAG_WORDS;
+  static constexpr uint32_t PIECE_WORDS = K3 ? 5u * 6u * FPS_WORDS : 0u;   // K3: the six partial products of up to five products
+  static constexpr uint32_t FLAG_WORDS = 32u;         // [level * 8 + task]: bit 0 the a operand is zero, bit 1 the b operand (K3: see there)
+  static constexpr uint32_t GROUP_WORDS = (K3 ? FVK_COUNT : FV_COUNT) * VAL_WORDS + PIECE_WORDS + FLAG_WORDS;
   static constexpr uint32_t WAVE_WORDS = PER_WAVE * GROUP_WORDS;
 };
 
@@ -139,6 +147,167 @@ __device__ __forceinline__ void flow_mul(Fp<F::MOD>& r, const Fp<F::MOD> (&X)[F:
   }
 }
 
+// ---- Fq3, Karatsuba form ----------------------------------------------------------------------------------------------------------
+// The fused form above gives a lane one component of an Fq3 product: three base-field products and a reduction (fp_mul3, ~2.3 x the
+// time of fp_mul), four of them deep.  Karatsuba (fp3.tcc:83-96) splits a product into SIX base-field products that need nothing of
+// each other: a round is then
+//     P  lane (product m, piece j): v_j = A_j B_j,  A_0..5 = a0, a1, a2, a1 + a2, a0 + a1, a0 + a2  (B likewise)       one fp_mul
+//     R  lane (product m, component k): c0 = v0 + NR (v3 - v1 - v2),  c1 = v4 - v0 - v1 + NR v2,  c2 = v5 - v0 - v2 + v1   (branch-free:
+//        base = X - Y - Z with (X, Y, Z) picked by k, then S + [NR] T)
+//     D  the values the next round multiplies, component-wise: u, v after round 0;  A = uuZ - vvv - 2R and R - A after round 2;
+//        Y3 = Yt - W after round 3
+// with a barrier after each (one wave per block: free).  Every operand of a product is ONE stored value, so P prepares its operands
+// with at most one addition per side.  Same values mod p as the fused form and as the VM.
+struct FlowK3Prod { uint32_t a, b, dst; };
+__device__ __forceinline__ FlowK3Prod flow_k3_product(int level, uint32_t m) {
+  switch (level * 8 + (int)m) {
+    case 0: return {FV_X1, FV_Z2, FV_T0};
+    case 1: return {FV_Y1, FV_Z2, FV_T1};
+    case 2: return {FV_Z1, FV_Z2, FV_T2};
+    case 3: return {FV_X2, FV_Z1, FV_T3};
+    case 4: return {FV_Y2, FV_Z1, FV_T4};
+    case 8: return {FV_U, FV_U, FV_UU};
+    case 9: return {FV_V, FV_V, FV_VV};
+    case 16: return {FV_V, FV_VV, FV_VVV};
+    case 17: return {FV_VV, FV_T0, FV_R};
+    case 18: return {FV_UU, FV_T2, FV_UUZ};
+    case 24: return {FV_V, FV_A, FV_X3};
+    case 25: return {FV_U, FV_RA, FV_YT};
+    case 26: return {FV_VVV, FV_T1, FV_W};
+    default: return {FV_VVV, FV_T2, FV_Z3};
+  }
+}
+// piece j of the value at `val` (three components of 28 words): a0, a1, a2, a1 + a2, a0 + a1, a0 + a2
+template <int M>
+__device__ __forceinline__ void flow_k3_piece(Fp<M>& r, const uint32_t* val, uint32_t j) {
+  const uint32_t c_first = j < 3u ? j : (j == 3u ? 1u : 0u), c_second = j == 4u ? 1u : 2u;
+  fp_load(r, val + c_first * FPS_WORDS);
+  if (j >= 3u) {
+    Fp<M> y;
+    fp_load(y, val + c_second * FPS_WORDS);
+    fp_add(r, r, y);
+  }
+}
+template <class C>
+__device__ __forceinline__ void flow_add_k3(uint32_t* grp, uint32_t l, const uint32_t* srcS, const uint32_t* srcT, bool emptyS, bool emptyT,
+                                            uint32_t* dst, bool live) {
+  using FL = Flow<C>;
+  using F = typename C::F;
+  constexpr int M = FL::M;
+  constexpr uint32_t VW = FL::VAL_WORDS;
+  uint32_t* pieces = grp + FVK_COUNT * VW;
+  uint32_t* flags = pieces + FL::PIECE_WORDS;        // [0..2] Z1 component zero, [3..5] Z2, [6..8] u, [9..11] v
+  if (l < 18u) {
+    const bool second = l >= 9u;
+    const uint32_t e = second ? l - 9u : l;
+    Fp<M> x;
+    if (!live || (second ? emptyT : emptyS)) {
+      if (e == 3u) fp_one(x); else fp_zero(x);          // (0 : 1 : 0)
+    } else {
+      fp_load(x, (second ? srcT : srcS) + e * FPS_WORDS);
+    }
+    fp_store(grp + l * FPS_WORDS, x);
+    if (e >= 6u) flags[(second ? 3u : 0u) + e - 6u] = fp_is_zero(x) ? 1u : 0u;
+  }
+  __syncthreads();
+#pragma nounroll
+  for (int level = 0; level < FLOW_LEVELS; ++level) {
+    const uint32_t nprod = flow_tasks_of(level);
+    {                                                  // P
+      const uint32_t m = l / 6u, j = l - m * 6u;
+      if (m < nprod) {
+        const FlowK3Prod pr = flow_k3_product(level, m);
+        Fp<M> a, b, r;
+        flow_k3_piece<M>(a, grp + pr.a * VW, j);
+        if (pr.b == pr.a) b = a; else flow_k3_piece<M>(b, grp + pr.b * VW, j);
+        fp_mul(r, a, b);
+        fp_store(pieces + (m * 6u + j) * FPS_WORDS, r);
+      }
+    }
+    __syncthreads();
+    {                                                  // R
+      const uint32_t m = l / 3u, k = l - m * 3u;
+      if (m < nprod) {
+        const FlowK3Prod pr = flow_k3_product(level, m);
+        const uint32_t* v = pieces + m * 6u * FPS_WORDS;
+        // base = X - Y - Z:  k = 0: v3 - v1 - v2;  k = 1: v4 - v0 - v1;  k = 2: v5 - v0 - v2
+        const uint32_t ix = 3u + k, iy = k == 0u ? 1u : 0u, iz = k == 1u ? 1u : 2u, iw = k == 0u ? 0u : (k == 1u ? 2u : 1u);
+        Fp<M> base, y, w, t, n, sum;
+        fp_load(base, v + ix * FPS_WORDS);
+        fp_load(y, v + iy * FPS_WORDS);
+        fp_sub(base, base, y);
+        fp_load(y, v + iz * FPS_WORDS);
+        fp_sub(base, base, y);
+        fp_load(w, v + iw * FPS_WORDS);
+        // c_k = S + [NR] T:  k = 0: v0 + NR base;  k = 1: base + NR v2;  k = 2: base + v1
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.l[i] = k == 0u ? base.l[i] : w.l[i];
+        fp_mul_small(n, t, F::NONRES);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { n.l[i] = k == 2u ? t.l[i] : n.l[i]; t.l[i] = k == 0u ? w.l[i] : base.l[i]; }
+        fp_add(sum, t, n);
+        fp_store(grp + pr.dst * VW + k * FPS_WORDS, sum);
+      }
+    }
+    __syncthreads();
+    if (level != 1) {                                  // D (nothing to derive after the squarings)
+      const uint32_t q = l / 3u, k = l - q * 3u;
+      if (level == 0 && q < 2u) {                      // u = t4 - t1, v = t3 - t0
+        Fp<M> x, y;
+        fp_load(x, grp + (q == 0u ? FV_T4 : FV_T3) * VW + k * FPS_WORDS);
+        fp_load(y, grp + (q == 0u ? FV_T1 : FV_T0) * VW + k * FPS_WORDS);
+        fp_sub(x, x, y);
+        fp_store(grp + (q == 0u ? FV_U : FV_V) * VW + k * FPS_WORDS, x);
+        flags[6u + q * 3u + k] = fp_is_zero(x) ? 1u : 0u;
+      } else if (level == 2 && q == 0u) {              // A = uuZ - vvv - 2R,  R - A
+        Fp<M> a, y, rr;
+        fp_load(a, grp + FV_UUZ * VW + k * FPS_WORDS);
+        fp_load(y, grp + FV_VVV * VW + k * FPS_WORDS);
+        fp_sub(a, a, y);
+        fp_load(rr, grp + FV_R * VW + k * FPS_WORDS);
+        fp_sub(a, a, rr);
+        fp_sub(a, a, rr);
+        fp_store(grp + FV_A * VW + k * FPS_WORDS, a);
+        fp_sub(rr, rr, a);
+        fp_store(grp + FV_RA * VW + k * FPS_WORDS, rr);
+      } else if (level == 3 && q == 0u) {              // Y3 = Yt - W
+        Fp<M> x, y;
+        fp_load(x, grp + FV_YT * VW + k * FPS_WORDS);
+        fp_load(y, grp + FV_W * VW + k * FPS_WORDS);
+        fp_sub(x, x, y);
+        fp_store(grp + FV_Y3 * VW + k * FPS_WORDS, x);
+      }
+      __syncthreads();
+    }
+  }
+  const bool zS = (flags[0] & flags[1] & flags[2]) != 0, zT = (flags[3] & flags[4] & flags[5]) != 0;
+  const bool same = (flags[6] & flags[7] & flags[8] & flags[9] & flags[10] & flags[11]) != 0;
+  if (!live) return;
+  if (zS || zT) {
+    if (l < 9u) {
+      Fp<M> x;
+      fp_load(x, grp + ((zT ? 0u : 9u) + l) * FPS_WORDS);
+      fp_store(dst + l * FPS_WORDS, x);
+    }
+  } else if (same) {
+    using V = typename SplitOf<C>::type;
+    const uint32_t lane = threadIdx.x & 63u, base = lane - l;
+    const uint32_t first = ((base + 2u) / 3u) * 3u;
+    if (lane >= first && lane < first + 3u) {
+      Proj<V> P, Q;
+      proj_load<V>(P, grp);
+      proj_load<V>(Q, grp + 3u * VW);
+      pt_vm_add_outlined<V>(P, Q, PC_ADD);
+      proj_store<V>(dst, P);
+    }
+  } else if (l < 9u) {
+    const uint32_t q = l / 3u, k = l - q * 3u;
+    Fp<M> x;
+    fp_load(x, grp + (q == 0u ? FV_X3 : (q == 1u ? FV_Y3 : FV_Z3)) * VW + k * FPS_WORDS);
+    fp_store(dst + l * FPS_WORDS, x);
+  }
+}
+
 // dst = S + T by the G lanes of one group.  grp: the group's LDS block; l: this thread's lane in the group.  Every thread of the
 // (one-wave) block must call it: there are barriers inside.  live == false: a group without an addition (it computes on identities
 // and stores nothing).  emptyS / emptyT: the operand is the identity whatever memory holds (a bucket no entry was sorted into).
@@ -150,6 +319,10 @@ __device__ __forceinline__ void flow_add(uint32_t* grp, uint32_t l, const uint32
   using F = typename C::F;
   constexpr int D = FL::D, M = FL::M;
   constexpr uint32_t UD = (uint32_t)D;
+  if constexpr (FL::K3) {
+    flow_add_k3<C>(grp, l, srcS, srcT, emptyS, emptyT, dst, live);
+    return;
+  }
   uint32_t* flags = grp + FV_COUNT * FL::VAL_WORDS;
   for (uint32_t f = l; f < 6u * UD; f += FL::G) {
     const bool second = f >= 3u * UD;

@@ -628,7 +628,8 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
     // MNT753_EDGE_FLOW_NODES additions (default 32768 for the base fields, 16384 for Fq2 / Fq3; estimated as lanes / 2^l: one node
     // per lane boundary at the first level, half as many per level after it) spreads each addition over a group of lanes, the levels
     // before it run one VM addition per lane over the list.  MNT753_FLOW=0: the slot-driven levels of the first tree (no lists).
-    const uint64_t flow_edge_nodes = getenv("MNT753_EDGE_FLOW_NODES") ? strtoull(getenv("MNT753_EDGE_FLOW_NODES"), nullptr, 10) : (C::F::DEG == 1 ? 32768 : 16384);
+    const uint64_t flow_edge_nodes = getenv("MNT753_EDGE_FLOW_NODES") ? strtoull(getenv("MNT753_EDGE_FLOW_NODES"), nullptr, 10)
+                                     : (C::F::DEG == 1 ? 32768 : (Flow<C>::K3 ? 8192 : 16384));   // (K3: two additions per wave, 2048 per round)
     uint32_t* counts = b->d_edge_flags + 40;               // nodes of level l, behind the 40 flags
     uint4* lists[2] = {reinterpret_cast<uint4*>(b->d_edge_tmp), reinterpret_cast<uint4*>(b->d_edge_tmp) + acc_lanes};   // the old merge's temporary: 2 x lanes entries fit many times
     uint32_t parity = 0;
@@ -700,7 +701,7 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
     // the narrowest steps: one group of lanes per addition (four products deep instead of fourteen / eight), up to the number of
     // additions at which the kernels below, with more additions per wave, catch up (MNT753_REDUCE_FLOW_MAX moves it)
     const uint64_t flow_max = !flow_enabled() ? 0 : getenv("MNT753_REDUCE_FLOW_MAX") ? strtoull(getenv("MNT753_REDUCE_FLOW_MAX"), nullptr, 10)
-                              : (C::F::DEG == 3 ? 16384 : (C::F::DEG == 2 ? 4096 : 8192));
+                              : (C::F::DEG == 3 ? (Flow<C>::K3 ? 8192 : 16384) : (C::F::DEG == 2 ? 4096 : 8192));
     for (uint32_t step = 0; step < k; ++step) {
       const uint64_t items = (uint64_t)NS * red_items(k, step);
       if (items <= flow_max) {
