@@ -113,7 +113,9 @@ def test_synthetic_inputs(pkg, curve, group):
 def test_device_field_arithmetic_compiled_for_the_host(tmp_path):
     """fp753.hip.h is __host__ __device__: the fused multipliers of the lane-split extension fields (fp_mul2, fp_mul3) and
     the dedicated squaring (fp_sqr) must agree with compositions of the plain Montgomery product fp_mul -- which the
-    oracle-pinned GPU parity tests cover -- and keep their results in [0, 2p).  2000 random cases per modulus."""
+    oracle-pinned GPU parity tests cover -- and keep their results in [0, 2p).  2000 random cases per modulus.  Also there: the lazy
+    arithmetic of the pairing levels, and (round 4) the carry-free butterflies of the NTT -- two stages on raw signed limbs and one
+    normalisation -- against the eager formulas on inputs at the edges of their stated ranges, with the limb bounds asserted."""
     import subprocess
     exe = tmp_path / "host_fp_check"
     src = os.path.join(ROOT, "tools", "host_fp_check.cpp")

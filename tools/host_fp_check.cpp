@@ -82,4 +82,44 @@ template <int M> int run_lazy() {
   }
   return bad;
 }
-int main() { int b = run<0>() + run<1>() + run_lazy<0>() + run_lazy<1>(); printf(b ? "FAIL %d\n" : "fp_sqr / fp_mul2 / fp_mul3 / fp_inv / lazy arithmetic OK\n", b); return b != 0; }
+// The carry-free butterflies of the NTT (ntt_kernels.hip.h, k_ntt_group): two stages (the second on the raw outputs of the first) and
+// ONE normalisation per element, against eager fp_mul / fp_add / fp_sub; inputs at the edges of what the kernel can hand a stage
+// pair -- [0, 1.51p) after fp_norm, [0, p) after fp_unpack, below 1.44p behind an in_scale product --, twiddles anywhere in [0, 2p).
+// Checked: the same values mod p, every raw limb below 2^30 in magnitude, the normalised outputs inside [0, 2p) with 28-bit limbs.
+template <int M> bool limbs_below(const Fp<M>& a, int bits) {
+  for (int i = 0; i < NL; ++i) { const int64_t v = (int32_t)a.l[i]; if (v >= ((int64_t)1 << bits) || v <= -((int64_t)1 << bits)) return false; }
+  return true;
+}
+template <int M> int run_ntt_lazy() {
+  int bad = 0;
+  Fp<M> pm1, z, one; fp_zero(z); fp_one(one); fp_sub(pm1, z, one);   // p - 1 (in [0, 2p))
+  for (int it = 0; it < 4000; ++it) {
+    // four elements of one 4-point sub-transform, two twiddle stages
+    Fp<M> x[4], e[4], w1, w2, w3;
+    for (int i = 0; i < 4; ++i) { rand_fp(x[i]); if ((it & 7) == 1) x[i] = pm1; fp_norm(x[i], x[i]); e[i] = x[i]; }   // normalised: [0.49p, 1.51p)
+    if ((it & 7) == 2) for (int i = 0; i < 4; ++i) { Fp<M> c; fp_canon(c, x[i]); x[i] = c; e[i] = c; }              // canonical: [0, p)
+    rand_fp(w1); rand_fp(w2); rand_fp(w3);
+    if ((it & 3) == 3) { Fp<M> two_p_minus; fp_sub(two_p_minus, z, one); fp_add(w1, two_p_minus, pm1); }              // a twiddle near the top of [0, 2p)
+    // eager
+    Fp<M> t, a0, a1, a2, a3;
+    fp_mul(t, w1, e[1]); fp_add(a0, e[0], t); fp_sub(a1, e[0], t);
+    fp_mul(t, w1, e[3]); fp_add(a2, e[2], t); fp_sub(a3, e[2], t);
+    Fp<M> b0, b1, b2, b3;
+    fp_mul(t, w2, a2); fp_add(b0, a0, t); fp_sub(b2, a0, t);
+    fp_mul(t, w3, a3); fp_add(b1, a1, t); fp_sub(b3, a1, t);
+    // carry-free: stage A raw, stage B raw on those, one normalisation
+    Fp<M> r0, r1, r2, r3, s0, s1, s2, s3;
+    fp_mul_s(t, w1, x[1]); fp_sub_raw(r1, x[0], t); fp_addsub_raw(r0, x[0], t, false);
+    fp_mul_s(t, w1, x[3]); fp_sub_raw(r3, x[2], t); fp_addsub_raw(r2, x[2], t, false);
+    if (!limbs_below(r0, 30) || !limbs_below(r1, 30) || !limbs_below(r2, 30) || !limbs_below(r3, 30)) { ++bad; if (bad < 6) printf("ntt lazy: stage A limb out of range M=%d\n", M); }
+    fp_mul_s(t, w2, r2); fp_sub_raw(s2, r0, t); fp_addsub_raw(s0, r0, t, false);
+    fp_mul_s(t, w3, r3); fp_sub_raw(s3, r1, t); fp_addsub_raw(s1, r1, t, false);
+    if (!limbs_below(s0, 30) || !limbs_below(s1, 30) || !limbs_below(s2, 30) || !limbs_below(s3, 30)) { ++bad; if (bad < 6) printf("ntt lazy: stage B limb out of range M=%d\n", M); }
+    fp_norm(s0, s0); fp_norm(s1, s1); fp_norm(s2, s2); fp_norm(s3, s3);
+    if (!eq(s0, b0) || !eq(s1, b1) || !eq(s2, b2) || !eq(s3, b3) || !in_range(s0) || !in_range(s1) || !in_range(s2) || !in_range(s3)) {
+      ++bad; if (bad < 6) printf("ntt lazy butterfly mismatch M=%d it=%d\n", M, it);
+    }
+  }
+  return bad;
+}
+int main() { int b = run<0>() + run<1>() + run_lazy<0>() + run_lazy<1>() + run_ntt_lazy<0>() + run_ntt_lazy<1>(); printf(b ? "FAIL %d\n" : "fp_sqr / fp_mul2 / fp_mul3 / fp_inv / lazy arithmetic / carry-free NTT butterflies OK\n", b); return b != 0; }
