@@ -130,7 +130,7 @@ int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective);
  * as early as it can.  Without it the two interleave, finish together, and both latency-bound tails (edge merge, bucket reduction:
  * 1.3 - 3 ms of a 2^20-point MSM during which the chip idles) end the prove; with it first's tail runs under b's point kernels and
  * only b's is left -- so the MSM with the shortest tail goes last (A behind C in the prove: cuda_prover_piecewise.cu:71-81 starts
- * them in an order that does not matter there).  Worth it for the small sets (MNT6753 2^15: 15.7 -> 15.2 ms per proof); two
+ * them in an order that does not matter there).  Worth 1 - 3 % for the small sets (MNT6753 2^15: 15.7 -> 15.2 and 15.3 -> 15.2 ms per proof in two series); two
  * 2^20-point MSMs gain more from filling each other's kernel ends interleaved (measured 157.2 -> 158.4 ms ordered), so the wrapper
  * orders only below 2^18 points.  Both sets on one device; call it after first's mnt753_msm_start. */
 int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first);

@@ -808,7 +808,8 @@ static void compact_in_rank_order(PendingMsm& pm) {
 // The MSM for C (three times the points of A's) is started first and has the longer latency-bound tail; the next MSM started on a
 // device is ordered behind C's point kernels there (mnt753_msm_order_after): C's tail then runs under that MSM's point kernels instead
 // of ending the prove beside it (g_gate, above).
-// Measured (profiles/r04/prove_msm_order.txt, alternating on one box): MNT6753 2^15 15.7 -> 15.2 ms; MNT4753 2^20 157.2 -> 158.4 ms
+// Measured (profiles/r04/prove_msm_order.txt, alternating on one box): MNT6753 2^15 15.7 -> 15.2 ms in one series, 15.3 -> 15.2 in a
+// second; MNT4753 2^20 157.2 -> 158.4 ms
 // -- there the two MSMs interleaved fill each other's kernel ends, which is worth more than a hidden 3 ms tail -- so only the small
 // sets are ordered (C over at most 2^18 points on the device).  MNT753_ORDER_MSMS=0: never, =2: always.
 static int order_msms() {
@@ -816,7 +817,7 @@ static int order_msms() {
   return mode;
 }
 static void gate_set(int g, mnt753_bases* c) {
-  if (order_msms() == 0 || (order_msms() == 1 && mnt753_bases_size(c) > ((size_t)1 << 18))) return;
+  if (order_msms() == 0 || (order_msms() != 2 && mnt753_bases_size(c) > ((size_t)1 << 18))) return;
   if (g_gate.size() <= (size_t)g) g_gate.resize((size_t)g + 1, nullptr);
   g_gate[(size_t)g] = c;
 }
@@ -841,9 +842,10 @@ static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarS
       check(mnt753_copy_peer_async(g, part.scalars->ptr, src.home, src.home_ptr() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
       sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
     }
-    if (!is_c) gate_apply(g, part.set->h);
+    // mode 4 (development): every MSM of a small set behind the one started before it on the device (G2 -> C -> A), not only A behind C
+    if (!is_c || order_msms() == 4) gate_apply(g, part.set->h);
     check(mnt753_msm_start(part.set->h, 0, sc, 1, hi - lo, nullptr), what);
-    if (is_c) gate_set(g, part.set->h);
+    if (is_c || (order_msms() == 4 && mnt753_bases_size(part.set->h) <= ((size_t)1 << 18))) gate_set(g, part.set->h);
     pend->sets[(size_t)g] = part.set;
   }
   // rank order for the fold (multiexp.tcc:433-438), whatever the order of enqueueing was
