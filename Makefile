@@ -6,9 +6,14 @@ BUILD := build
 HIPCC ?= hipcc
 HIPFLAGS := -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-result
 LIB   := $(PKG)/libmnt753_hip.so
+# test infrastructure beside the product (include/mnt753_hip_test.h): synthetic bases with known discrete logarithms, device-level
+# known-answer hooks.  Links against the product library; nothing of the product links against it.
+TESTLIB := $(PKG)/libmnt753_hip_test.so
 
-HIP_SRCS := mnt753_core.hip mnt753_msm.hip msm_sort.hip msm_inst_mnt4g1.hip msm_inst_mnt4g2.hip msm_inst_mnt6g1.hip msm_inst_mnt6g2.hip mnt753_fft.hip mnt753_synth.hip mnt753_testhooks.hip mnt753_r1cs.hip mnt753_exchange.hip
+HIP_SRCS := mnt753_core.hip mnt753_msm.hip msm_sort.hip msm_inst_mnt4g1.hip msm_inst_mnt4g2.hip msm_inst_mnt6g1.hip msm_inst_mnt6g2.hip mnt753_fft.hip mnt753_synth.hip mnt753_r1cs.hip mnt753_exchange.hip
 HIP_OBJS := $(addprefix $(BUILD)/,$(HIP_SRCS:.hip=.o))
+TEST_SRCS := mnt753_testhooks.hip mnt753_synth_points.hip
+TEST_OBJS := $(addprefix $(BUILD)/,$(TEST_SRCS:.hip=.o))
 HDRS := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.hip.h $(CSRC)/*.h include/*.h)
 
 HOST := $(PKG)/host
@@ -16,7 +21,7 @@ MAIN := $(PKG)/main_hip
 
 LAZY_TEST := $(PKG)/lazy_c_test
 
-all: $(LIB) $(MAIN) $(LAZY_TEST) oracle
+all: $(LIB) $(TESTLIB) $(MAIN) $(LAZY_TEST) oracle
 
 # the wrapper's expression fusion from the caller's side (tools/host_tests/lazy_c_test.cpp; run by tests/test_prover_gpu.py)
 $(LAZY_TEST): tools/host_tests/lazy_c_test.cpp $(HOST)/prover_hip_functions.cpp include/prover_hip_functions.hpp include/mnt753_hip.h $(LIB)
@@ -27,13 +32,20 @@ $(MAIN): $(HOST)/main.cpp $(HOST)/prover_hip_functions.cpp include/prover_hip_fu
 
 # per-object dependency files (-MMD): a change to one header rebuilds the translation units that include it, not all of them
 # (the point-kernel units take minutes each)
-$(BUILD)/%.o: $(CSRC)/%.hip
+# (an object left over from before the .d files existed has none: it then depends on every header, as it used to)
+.SECONDEXPANSION:
+$(BUILD)/%.o: $(CSRC)/%.hip $$(if $$(wildcard $(BUILD)/$$*.d),,$$(HDRS))
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -MMD -MP -c $< -o $@
--include $(HIP_OBJS:.o=.d)
+-include $(HIP_OBJS:.o=.d) $(TEST_OBJS:.o=.d)
 
+# -soname: the test library (and anything else) names the product by its soname, so a development variant loaded from another
+# directory (MNT753_LIB) satisfies it instead of a second copy of the product being mapped beside it
 $(LIB): $(HIP_OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS) -ldl
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libmnt753_hip.so -o $@ $(HIP_OBJS) -ldl
+
+$(TESTLIB): $(TEST_OBJS) $(LIB)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libmnt753_hip_test.so -o $@ $(TEST_OBJS) -L$(PKG) -lmnt753_hip -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle
@@ -51,7 +63,7 @@ $(BUILD)/san/main_hip_tsan: $(SAN_SRCS) include/prover_hip_functions.hpp include
 	g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -o $@ $(SAN_SRCS)
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(MAIN) $(LAZY_TEST)
+	rm -rf $(BUILD) $(LIB) $(TESTLIB) $(MAIN) $(LAZY_TEST)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean asan tsan

@@ -48,7 +48,7 @@ LOG_N = 20
 ALGO_BYTES_PER_PAIR = 288          # 192 B affine G1 base + 96 B scalar, read once
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
 MODMUL_PEAK_PER_S = 22.0e9         # measured chip peak of the 753-bit Montgomery multiplier (profiles/r01/mulbench_mi355x.txt)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def sha256_file(path):
@@ -192,7 +192,7 @@ def live_traffic():
         d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-prove", "--no-extras", "--no-traffic"]
+                   "--no-cpu-baseline", "--no-prove", "--no-extras", "--no-traffic", "--no-exchange"]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if r.returncode != 0 or not dbs:
@@ -280,7 +280,13 @@ def _run_ref_main(curve_name, pp, ip, op):
             "timing_window": "libsnark/main.cpp:203-270, printed at :270"}, sha256_file(op)
 
 
-def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3):
+def _prover_times(stdout):
+    m1 = re.findall(r"Total time from input to output: ([0-9.]+)s", stdout)
+    m2 = re.search(r"load params: ([0-9.]+)s", stdout)
+    return [float(x) for x in m1], (float(m2.group(1)) if m2 else None)
+
+
+def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, share=False, cold=True):
     """main_hip on the seeded synthetic files; hash compared with the reference-minted one (or, where no hash was minted for
     the size, with the bytes the reference prover writes here, cpu=True).
 
@@ -292,8 +298,11 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3):
     expected = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_hashes.json"))).get(key)
     work = tempfile.mkdtemp(prefix="bench_prove_", dir=os.environ.get("TMPDIR", "/tmp"))
     pp, ip, op, oc = (os.path.join(work, k) for k in ("params", "input", "output", "output_cpu"))
-    out = {"curve": curve_name, "log2_d": log2_d}
+    out = {"curve": curve_name, "log2_d": log2_d, "n_gpus": gpus}
     cpu_out = None
+    dev_flags = ["--gpus", str(gpus)] if gpus > 1 else []
+    # BENCH_SHARE_GPU=1 (development, the one-GPU test box): the logical devices of the sharded prover share the visible GPU
+    child_env = dict(os.environ, MNT753_SHARE_DEVICE="1") if share and gpus > 1 else dict(os.environ)
     try:
         t0 = time.time()
         g = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "synth_files.py"), curve_name, str(log2_d), pp, ip], capture_output=True, text=True)
@@ -306,7 +315,7 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3):
         t0 = time.time()
         # `repeat` proofs of the same input in ONE process: the first is the reference's metric (fresh process, parameters loaded,
         # then input -> output); the others show what a resident prover pays per proof
-        r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", str(repeat)], capture_output=True, text=True)
+        r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", str(repeat)] + dev_flags, capture_output=True, text=True, env=child_env)
         wall = time.time() - t0
         if r.returncode != 0:
             out.update(error=r.stderr[-400:], parity_ok=False)
@@ -329,6 +338,35 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3):
             out.update(sha256_expected=expected["output_sha256"], synthetic_files_match_minted=files_ok,
                        parity_ok=bool(files_ok) and sha == expected["output_sha256"],
                        expected_from="tests/golden/oracle_hashes.json: oracle/_ref/main (the reference, bos_coster) on the same seeded files")
+        if gpus > 1:
+            out["sharding"] = (f"main_hip --gpus {gpus}: every parameter vector cut into {gpus} contiguous slices, one MSM per slice and device, partial points "
+                               "folded in rank order (multiexp.tcc:417-440); compute_H spread over devices 0 / 1 / 2" + ("; logical devices share ONE GPU (development)" if share else ""))
+        # the same files through further children: (a) a COLD process -- no warm-up MSM at parameter-load time, the reference's literal
+        # metric (main.cpp:196-203: parameters loaded, nothing run yet); (b) with several devices, the fold over RCCL inside the boundary
+        side = []
+        if cold:
+            side.append(("cold_process", ["--repeat", "2"], {"MNT753_NO_WARMUP": "1"},
+                         "MNT753_NO_WARMUP=1: B::read_params builds the tables but runs nothing; the first proof pays first-touch page faults and code loading"))
+        if gpus > 1:
+            side.append(("fold_rccl", ["--repeat", "2", "--fold", "rccl"], {"MNT753_TRACE": "1"},
+                         "partial points through mnt753_exchange_points (ncclAllGather over the prover's devices) in front of the serial fold"))
+        for key, flags, env_extra, note in side:
+            for q in (op,):
+                if os.path.exists(q):
+                    os.remove(q)
+            t0 = time.time()
+            r2 = subprocess.run([exe, curve_name, "compute", pp, ip, op] + flags + dev_flags, capture_output=True, text=True, env=dict(child_env, **env_extra))
+            if r2.returncode != 0:
+                out[key] = {"error": r2.stderr[-300:]}
+                continue
+            ts, lp = _prover_times(r2.stdout)
+            sha2 = sha256_file(op)
+            out[key] = {"input_to_output_s": ts[0] if ts else None, "input_to_output_s_all": ts, "load_params_s": lp, "wall_incl_params_s": round(time.time() - t0, 3),
+                        "same_bytes": sha2 == sha, "note": note}
+            if key == "fold_rccl":
+                out[key]["folded"] = "over RCCL" if "over RCCL" in r2.stderr else ("on the host (no communicator: " + ("logical devices share a GPU" if share else "librccl unavailable") + ")")
+            if sha2 != sha:
+                out["parity_ok"] = False
         if cpu:
             cpu_out, cpu_sha = _run_ref_main(curve_name, pp, ip, oc)
             cpu_out.update(curve=curve_name, log2_d=log2_d, sha256=cpu_sha, same_bytes_as_gpu=(cpu_sha == sha) if cpu_sha else None)
@@ -346,9 +384,14 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3):
     return out, cpu_out
 
 
-def prove_legs():
-    """All the prove legs of the bench line, before this process touches the GPU."""
+def prove_legs(gpus=1, share=False, log2_d4=20, log2_d6=15):
+    """All the prove legs of the bench line, before this process touches the GPU.  gpus > 1: main_hip --gpus N (no CPU provers: the
+    N = 1 line carries them)."""
     legs = {}
+    if gpus > 1:
+        legs["prove"], _ = prove_leg(log2_d4, "MNT4753", gpus=gpus, share=share)
+        legs["prove_mnt6753"], _ = prove_leg(log2_d6, "MNT6753", gpus=gpus, share=share)
+        return legs
     want_cpu = os.environ.get("BENCH_CPU_PROVE", "1") != "0"
     # BASELINE.json's metric is the prove time on the FULL MNT4753 parameters "next to the CPU ./main baseline timed on the same box's
     # host cores": the reference's own prover runs the same 2^20 files right after main_hip (libsnark/main.cpp:203-270; minutes of CPU
@@ -380,6 +423,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the FFT / compute_H / G2 / table-less legs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure the HBM traffic of the dominant phase")
     ap.add_argument("--no-exchange", action="store_true", help="skip the RCCL exchange-latency leg")
+    ap.add_argument("--prove-log2-d", type=int, nargs=2, default=None, metavar=("MNT4753", "MNT6753"),
+                    help="sizes of the prove legs (default 20 15 = the metric's; tests pass sizes with a minted hash, e.g. 14 10); runs them whatever --log-n is")
     ap.add_argument("--exchange-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--exchange-probe-abi", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -397,15 +442,36 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); run `python bench.py --gpus N` or torchrun with --nproc-per-node N")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-    # the full-prove leg first, in child processes, while this process has not touched the GPU yet (see prove_leg)
+    # A profiled run (rocprofv3 preloads its library, which initialises the GPU before main) must not start further GPU children: no
+    # prove legs, no exchange probes, no PMC passes under the profiler.
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    # the full-prove leg first, in child processes, while NO rank has touched a GPU yet (see prove_leg).  N > 1: rank 0 runs
+    # `main_hip ... --gpus N` (one process over the N devices); the other ranks wait on a CPU-side barrier -- a file named after the
+    # launcher (same parent process and rendezvous port for all ranks of one launch).
     legs = None
-    if world == 1 and not args.no_prove and args.log_n == LOG_N:
-        legs = prove_legs()
+    want_prove = not args.no_prove and not under_profiler and (args.log_n == LOG_N or args.prove_log2_d is not None)
+    d4, d6 = args.prove_log2_d if args.prove_log2_d else (20, 15)
+    if want_prove and world == 1:
+        legs = prove_legs() if args.prove_log2_d is None else {"prove": prove_leg(d4, "MNT4753")[0], "prove_mnt6753": prove_leg(d6, "MNT6753")[0], "cpu_prove": []}
+    elif want_prove:
+        gate = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bench_prove_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.done")
+        if rank == 0:
+            try:
+                legs = prove_legs(world, share, d4, d6)
+            finally:
+                with open(gate, "w") as f:
+                    f.write("done\n")
+        else:
+            t_wait = time.time()
+            while not os.path.exists(gate):
+                if time.time() - t_wait > 3600:
+                    raise SystemExit("bench.py: rank 0's prove legs did not finish within an hour")
+                time.sleep(0.2)
     exchange = None
-    if world == 1 and not args.no_exchange and args.log_n == LOG_N:
+    if world == 1 and not args.no_exchange and args.log_n == LOG_N and not under_profiler:
         exchange = exchange_leg()
     traffic_live = None
-    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
     if world == 1 and not args.no_traffic and args.log_n == LOG_N and not under_profiler:   # (a profiled run has the GPU initialised already)
         traffic_live = live_traffic()
 
@@ -419,7 +485,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # BENCH_SHARE_GPU=1 (development only): all ranks share GPU 0 and exchange over gloo, to exercise the N > 1 flow
     # on a single-GPU box; the real multi-GPU run is one rank per GPU over RCCL.
-    share = os.environ.get("BENCH_SHARE_GPU") == "1"
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -553,9 +618,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            # ONE 2^20 array whatever N: the series over N = 1, 2, 4, 8 is a strong-scaling series and the N = 1 line is its first point
+            # (`weak`, N > 1 only, carries 2^20 points PER GPU)
+            "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "u64",
+            "dtype": "u32x27 limbs / u64 columns",
             "data": "synthetic",
             "parity_ok": ok,
             "config": {"workload": f"MNT4753 G1 Pippenger MSM, 2^{args.log_n} bases" + (f" split into {world} contiguous slices (one per GPU)" if world > 1 else "") +
@@ -604,6 +671,10 @@ def main():
             del os.environ["MNT753_MSM_PRECOMP"]
             _, e2, _ = timed(lambda: nt.msm(d_sc.data_ptr(), n=n, on_device=True, stream=stream), max(3, args.steps // 2), 1)
             extras["no_table_ms_per_step"] = e2 / max(3, args.steps // 2) * 1e3
+            # what `value` would be without the 9.4 GB window table per base set: beside the headline, not inside extras
+            line["no_window_table"] = {"value": n / (extras["no_table_ms_per_step"] * 1e-3), "unit": "points/s", "ms_per_step": extras["no_table_ms_per_step"],
+                                       "note": "same MSM with one bucket set per window (c = 16, W = 48) and no precomputed multiples: base sets below 4096 points, "
+                                               "or hosts that cannot keep ~56 GB of tables per MNT4753 parameter set resident"}
             nt.close()
             bases.close()
             # 2^20 FFT and compute_H over Fr(MNT4753): BASELINE configs[2]; 192 B algorithmic per element per transform
@@ -779,11 +850,17 @@ def main():
                 if c.get("same_bytes_as_gpu") is False:
                     ok = False
         line["parity_ok"] = ok
+    elif rank == 0 and legs is not None:
+        line.update(legs)
+        ok = ok and bool(legs["prove"].get("parity_ok")) and bool(legs["prove_mnt6753"].get("parity_ok"))
+        line["parity_ok"] = ok
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0 and want_prove and os.path.exists(gate):
+            os.remove(gate)
     if not ok:
         raise SystemExit("bench.py: PARITY FAILURE")
 

@@ -67,6 +67,16 @@ int mnt753_init_devices(int n_devices);
 int mnt753_device_count(void);
 int mnt753_set_device(int logical_device);
 int mnt753_get_device(void);   /* the calling thread's current logical device (0 before mnt753_set_device) */
+/* Peer access: after the call the copy engines and kernels of `device` may address the memory of `peer` directly
+ * (hipDeviceEnablePeerAccess), so that a copy between the two goes over their xGMI link instead of staging through host memory.
+ * *how (may be NULL) = MNT753_PEER_SAME (both logical devices are one GPU: MNT753_SHARE_DEVICE), MNT753_PEER_DIRECT, or
+ * MNT753_PEER_STAGED (the platform offers no peer access for the pair; copies still work, through the host).  Idempotent.
+ * mnt753_init_devices asks for every ordered pair; the wrapper asks again and says under MNT753_TRACE=1 what it got.  The one-GPU
+ * reference has nothing to compare (cuda_prover_piecewise.cu:24-34 keeps ca / cb / cc on one device); this is what the sharding of
+ * SURVEY.md section 8e adds.  A mnt753_copy_peer_async is a command of the DESTINATION's default queue: the destination's copy
+ * engine (ROCr's SDMA; a blit kernel on its CUs where SDMA is turned off) reads the source's memory over the link. */
+enum { MNT753_PEER_SAME = 0, MNT753_PEER_DIRECT = 1, MNT753_PEER_STAGED = 2 };
+int mnt753_enable_peer_access(int device, int peer, int* how);
 int mnt753_copy_peer(int dst_device, void* dev_dst, int src_device, const void* dev_src, size_t bytes);
 /* The same without blocking the host: the copy is enqueued on dst_device's default stream and starts after everything enqueued so
  * far on src_device's default stream (an event recorded there, waited for on the destination) -- how the slices of
@@ -132,7 +142,8 @@ int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective);
  * only b's is left -- so the MSM with the shortest tail goes last (A behind C in the prove: cuda_prover_piecewise.cu:71-81 starts
  * them in an order that does not matter there).  Worth 1 - 3 % for the small sets (MNT6753 2^15: 15.7 -> 15.2 and 15.3 -> 15.2 ms per proof in two series); two
  * 2^20-point MSMs gain more from filling each other's kernel ends interleaved (measured 157.2 -> 158.4 ms ordered), so the wrapper
- * orders only below 2^18 points.  Both sets on one device; call it after first's mnt753_msm_start. */
+ * orders only below 2^18 points.  Both sets on one device; call it after first's mnt753_msm_start.  The order refers to first's
+ * latest start AT THE TIME b starts; it is dropped (no wait) if `first` is freed before b's next start. */
 int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first);
 
 /* window size override (0 = automatic); returns previous value.  Tuning knob, not part of the reference. */
@@ -217,42 +228,14 @@ size_t mnt753_r1cs_num_variables(const mnt753_r1cs* r); /* m: dev_w of mnt753_r1
 size_t mnt753_r1cs_num_inputs(const mnt753_r1cs* r);
 int mnt753_r1cs_evaluate(mnt753_r1cs* r, const uint64_t* dev_w, uint64_t* dev_ca, uint64_t* dev_cb, uint64_t* dev_cc, size_t out_len, void* stream);
 
-/* ---- deterministic synthetic inputs (host) ---------------------------------------------------------
- * Stand-in for libsnark/generate_parameters.cpp on machines that have neither the reference nor its
- * parameter files: bases with known discrete logarithms base[k] = e_k * G, uniform scalars, and the exact
- * value of sum scalars[k] * base[k] computed from the e_k (one scalar multiplication) for parity checks
- * at sizes no CPU implementation finishes quickly. */
-int mnt753_synth_points(int curve, int group, uint64_t seed, size_t n, uint64_t* out_affine, int threads);
+/* ---- uniform scalars (host) ---------------------------------------------------------------------------
+ * n elements of Fr of the curve, uniform in [0, r) by rejection on 753-bit draws of a seeded SplitMix64, in wire form.  What the
+ * product needs them for: the scalars of the warm-up MSMs at parameter-load time (B::read_params) and the prover's second random
+ * element s of `main_hip complete` when no file names one (main.cpp:312-319 draws it with libff's random_element). */
 int mnt753_synth_scalars(int curve, uint64_t seed, size_t n, uint64_t* out_scalars);
-int mnt753_synth_expected_msm(int curve, int group, uint64_t seed, size_t n, const uint64_t* scalars, uint64_t* out_projective);
 
-/* ---- test hooks (tests/ only; not used by the prover) -------------------------------------------------
- * The device field layer element-wise on n pairs of Fp elements in wire form (host pointers in and out), for known-answer
- * tests against libff's Fp_model (depends/libff/libff/algebra/fields/fp.tcc:161-186 mul_reduce, :405-417 +=, :491-508 -=,
- * :641-685 invert, :227-238 as_bigint).  mod: 0 = modulus A (Fr of MNT4753 / Fq of MNT6753), 1 = modulus B.
- * op: 0 a*b, 1 a+b, 2 a-b, 3 a^-1 (0 -> 0), 4 as_bigint(a), 5 -a, 6 a^2 (dedicated squaring), 7 wire->device->wire,
- * 8 a*b + a*a (fused two-product multiplier), 9 13*a (small-constant multiplier). */
-int mnt753_test_field_op(int mod, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
-/* The coordinate field of G2 on the device, element-wise on n pairs of elements in wire form (c0 | c1 [| c2], host pointers):
- * Fq2 = Fq[u]/(u^2 - 13) on MNT4753 (depends/libff/libff/algebra/fields/fp2.tcc:79-90 mul, :118-126 squared, :129-142 inverse,
- * :58-70 + and -), Fq3 = Fq[u]/(u^3 - 11) on MNT6753 (fp3.tcc:83-96, :107-123, :126-143, :59-74).  split: 0 = the one-lane form
- * (Karatsuba through one multiplier instance), 1 = the lane-split form the G2 point kernels run (two / three lanes per element,
- * fused multi-product multipliers, ds_bpermute exchange).
- * op: 0 a*b, 1 a*a, 2 a^-1, 3 a+b, 4 a-b, 5 -a, 6 (a == b) as the element 1 or 0 (the zero test the kernels branch on). */
-int mnt753_test_ext_op(int curve, int split, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
-/* Every form of the group law the MSM kernels contain, on n pairs of points.  p_proj / q_proj / out_proj: projective X | Y | Z in
- * wire form (any representative; Z == 0 is the identity), host pointers.  group: MNT753_G1 / MNT753_G2; split (G2 only): 0 = one
- * lane per point, 1 = the lane-split configuration.  Reference: operator+ / mixed_add / dbl of mnt4753_G1 (depends/libff/libff/
- * algebra/curves/mnt753/mnt4753/mnt4753_g1.cpp:134-207, :265-313, :315-346), mnt4753_G2 (mnt4753_g2.cpp:150-223, :281-329,
- * :331-362), mnt6753_G1 (mnt6753_g1.cpp), mnt6753_G2 (mnt6753_g2.cpp:156-229, :287-335, :337-368).
- * op: 0 P + Q through the point VM (bucket reduction, edge merge);  1 2P through the VM (window table; equal points);
- *     2 P + Q with Q affine (Q's Z is taken as 1 unless 0) through the VM's mixed addition (bucket accumulation);
- *     3 the same as straight-line code (bucket accumulation of the base fields and the two-lane Fq2; other fields: as op 2);
- *     4 P + Q with two point-lanes per addition (narrow steps of the bucket reduction, edge merge of Fq3);
- *     5 P + Q as straight-line code (wide steps of the bucket reduction, base fields; other fields: as op 0);
- *     6 P + Q with one GROUP of lanes per addition (8 for the base fields, 16 for Fq2 / Fq3: the narrowest steps of the bucket
- *       reduction and the levels of the edge merge of a short lane list; split = 0 only). */
-int mnt753_test_point_op(int curve, int group, int split, int op, const uint64_t* p_proj, const uint64_t* q_proj, size_t n, uint64_t* out_proj);
+/* The synthetic base points with known discrete logarithms and the device-level test hooks are NOT part of this library: they live
+ * in libmnt753_hip_test.so (include/mnt753_hip_test.h), which tests/, bench.py and __graft_entry__.smoke() load beside it. */
 
 #ifdef __cplusplus
 }

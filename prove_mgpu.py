@@ -139,11 +139,14 @@ def main():
         t_h = None
         if rank == 0:
             t_h = torch.empty(12 * (d + 2), dtype=torch.int64, device=tdev)
-            torch.cuda.synchronize(tdev)
+            # only the stream that carries the dependency: recv orders the arrived cb / cc against torch's current stream, which is
+            # the null stream the library's transforms run on.  A device-wide synchronisation here would also wait for the w-MSMs
+            # (B2, A) on their own non-blocking streams and serialise every rank's C behind them.
+            torch.cuda.current_stream(tdev).synchronize()
             dom.compute_h_finish(vec["ca"].data_ptr(), vec["cb"].data_ptr(), vec["cc"].data_ptr(), t_h.data_ptr())
             pkg.lib().mnt753_sync(None)
         pkg.parallel.scatter_h_slices(dist, rank, world, d, t_h, h_mine, via_host=share)
-        torch.cuda.synchronize(tdev)
+        torch.cuda.current_stream(tdev).synchronize()    # the slice has arrived; the MSMs in flight are not waited for
         h_at = lambda i: h_mine.data_ptr() + 96 * (i - lh)
     if fused:
         # scalars of this rank's slice of the concatenated sum: h[lo_H, hi_H) | w[2 + lo_L, 2 + hi_L) | r * w[lo_B1, hi_B1)

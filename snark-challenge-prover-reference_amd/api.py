@@ -31,7 +31,9 @@ def lib():
     path = lib_path()
     if not os.path.exists(path):
         raise Mnt753Error(f"{path} not found: build the HIP extension first (make, or __graft_entry__.build())")
-    L = C.CDLL(path)
+    # RTLD_GLOBAL: the test library beside it (test_lib) names the product by its soname and must find THIS copy -- also when
+    # MNT753_LIB loaded a development variant from another directory
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     u64p, vp, sz, i = C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t, C.c_int
     sig = {
         "mnt753_init": (i, [i]),
@@ -39,6 +41,7 @@ def lib():
         "mnt753_device_count": (i, []),
         "mnt753_set_device": (i, [i]),
         "mnt753_get_device": (i, []),
+        "mnt753_enable_peer_access": (i, [i, i, C.POINTER(C.c_int)]),
         "mnt753_copy_peer": (i, [i, vp, i, vp, sz]),
         "mnt753_copy_peer_async": (i, [i, vp, i, vp, sz]),
         "mnt753_last_error": (C.c_char_p, []),
@@ -83,12 +86,7 @@ def lib():
         "mnt753_compute_h_chain": (i, [vp, vp, vp]),
         "mnt753_compute_h_finish": (i, [vp, vp, vp, vp, vp, vp]),
         "mnt753_domain_device": (i, [vp]),
-        "mnt753_synth_points": (i, [i, i, C.c_uint64, sz, u64p, i]),
         "mnt753_synth_scalars": (i, [i, C.c_uint64, sz, u64p]),
-        "mnt753_synth_expected_msm": (i, [i, i, C.c_uint64, sz, u64p, u64p]),
-        "mnt753_test_field_op": (i, [i, i, u64p, u64p, sz, u64p]),
-        "mnt753_test_ext_op": (i, [i, i, i, u64p, u64p, sz, u64p]),
-        "mnt753_test_point_op": (i, [i, i, i, i, u64p, u64p, sz, u64p]),
         "mnt753_r1cs_create": (i, [i, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "mnt753_r1cs_free": (i, [vp]),
         "mnt753_r1cs_domain_size": (sz, [vp]),
@@ -103,7 +101,37 @@ def lib():
     return L
 
 
-EXPORTS = None  # filled lazily by tests: the list of symbols include/mnt753_hip.h declares
+_TEST_LIB = None
+
+
+def test_lib_path():
+    return os.environ.get("MNT753_TEST_LIB") or os.path.join(_HERE, "libmnt753_hip_test.so")
+
+
+def test_lib():
+    """libmnt753_hip_test.so (include/mnt753_hip_test.h): synthetic bases with known discrete logarithms and the device-level
+    known-answer hooks.  Test infrastructure: tests/, bench.py and __graft_entry__.smoke() load it, the product never does."""
+    global _TEST_LIB
+    if _TEST_LIB is not None:
+        return _TEST_LIB
+    lib()   # the product first: the test library resolves set_error / require_device and the HIP state against it
+    path = test_lib_path()
+    if not os.path.exists(path):
+        raise Mnt753Error(f"{path} not found: build the HIP extension first (make, or __graft_entry__.build())")
+    L = C.CDLL(path)
+    u64p, sz, i = C.POINTER(C.c_uint64), C.c_size_t, C.c_int
+    sig = {
+        "mnt753_synth_points": (i, [i, i, C.c_uint64, sz, u64p, i]),
+        "mnt753_synth_expected_msm": (i, [i, i, C.c_uint64, sz, u64p, u64p]),
+        "mnt753_test_field_op": (i, [i, i, u64p, u64p, sz, u64p]),
+        "mnt753_test_ext_op": (i, [i, i, i, u64p, u64p, sz, u64p]),
+        "mnt753_test_point_op": (i, [i, i, i, i, u64p, u64p, sz, u64p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _TEST_LIB = L
+    return L
 
 
 def _check(rc, what):
@@ -344,7 +372,7 @@ def vec_subeq(curve, a_ptr, b_ptr, n, stream=None):
 def synth_points(curve, group, seed, n, threads=None):
     out = np.zeros((n, affine_words(curve, group)), dtype=np.uint64)
     threads = threads or min(64, os.cpu_count() or 1)
-    _check(lib().mnt753_synth_points(curve, group, seed, n, out.ctypes.data_as(C.POINTER(C.c_uint64)), threads), "mnt753_synth_points")
+    _check(test_lib().mnt753_synth_points(curve, group, seed, n, out.ctypes.data_as(C.POINTER(C.c_uint64)), threads), "mnt753_synth_points")
     return out
 
 
@@ -357,7 +385,7 @@ def synth_scalars(curve, seed, n):
 def synth_expected_msm(curve, group, seed, scalars):
     s, ps = _u64(scalars)
     out = np.zeros(projective_words(curve, group), dtype=np.uint64)
-    _check(lib().mnt753_synth_expected_msm(curve, group, seed, s.size // 12, ps, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_synth_expected_msm")
+    _check(test_lib().mnt753_synth_expected_msm(curve, group, seed, s.size // 12, ps, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_synth_expected_msm")
     return out
 
 
@@ -415,7 +443,7 @@ def test_field_op(mod, op, a, b=None):
     a, pa = _u64(a)
     b, pb = _u64(a if b is None else b)
     out = np.zeros_like(a)
-    _check(lib().mnt753_test_field_op(mod, op, pa, pb, a.size // 12, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_field_op")
+    _check(test_lib().mnt753_test_field_op(mod, op, pa, pb, a.size // 12, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_field_op")
     return out
 
 
@@ -425,7 +453,7 @@ def test_ext_op(curve, split, op, a, b=None):
     b, pb = _u64(a if b is None else b)
     out = np.zeros_like(a)
     words = 12 * (2 if curve == 0 else 3)
-    _check(lib().mnt753_test_ext_op(curve, int(split), op, pa, pb, a.size // words, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_ext_op")
+    _check(test_lib().mnt753_test_ext_op(curve, int(split), op, pa, pb, a.size // words, out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_ext_op")
     return out
 
 
@@ -434,7 +462,7 @@ def test_point_op(curve, group, split, op, p, q=None):
     p, pp = _u64(p)
     q, pq = _u64(p if q is None else q)
     out = np.zeros_like(p)
-    _check(lib().mnt753_test_point_op(curve, group, int(split), op, pp, pq, p.size // projective_words(curve, group),
+    _check(test_lib().mnt753_test_point_op(curve, group, int(split), op, pp, pq, p.size // projective_words(curve, group),
                                       out.ctypes.data_as(C.POINTER(C.c_uint64))), "mnt753_test_point_op")
     return out
 

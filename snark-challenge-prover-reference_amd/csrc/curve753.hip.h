@@ -12,6 +12,7 @@
 // 64 KB instruction cache instead of streaming ~160 KB of straight-line code per addition.
 #pragma once
 #include <type_traits>
+#include <utility>
 #include "fp753.hip.h"
 #include "fp_inv.hip.h"
 
@@ -41,6 +42,7 @@ struct FieldFp {
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
   static HD void neg(E& r, const E& a) { fp_neg(r, a); }
+  static HD void half(E& r, const E& a) { fp_half(r, a); }
   static HD bool is_zero(const E& a) { return fp_is_zero(a); }
   static HD void zero(E& r) { fp_zero(r); }
   static HD void one(E& r) { fp_one(r); }
@@ -95,6 +97,7 @@ struct FieldFp2 {
   static HD void add(E& r, const E& a, const E& b) { fp_add(r.c0, a.c0, b.c0); fp_add(r.c1, a.c1, b.c1); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r.c0, a.c0, b.c0); fp_sub(r.c1, a.c1, b.c1); }
   static HD void neg(E& r, const E& a) { fp_neg(r.c0, a.c0); fp_neg(r.c1, a.c1); }
+  static HD void half(E& r, const E& a) { fp_half(r.c0, a.c0); fp_half(r.c1, a.c1); }
   static HD bool is_zero(const E& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
   static HD void zero(E& r) { fp_zero(r.c0); fp_zero(r.c1); }
   static HD void one(E& r) { fp_one(r.c0); fp_zero(r.c1); }
@@ -149,6 +152,7 @@ struct FieldFp3 {
   static HD void add(E& r, const E& a, const E& b) { fp_add(r.c0, a.c0, b.c0); fp_add(r.c1, a.c1, b.c1); fp_add(r.c2, a.c2, b.c2); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r.c0, a.c0, b.c0); fp_sub(r.c1, a.c1, b.c1); fp_sub(r.c2, a.c2, b.c2); }
   static HD void neg(E& r, const E& a) { fp_neg(r.c0, a.c0); fp_neg(r.c1, a.c1); fp_neg(r.c2, a.c2); }
+  static HD void half(E& r, const E& a) { fp_half(r.c0, a.c0); fp_half(r.c1, a.c1); fp_half(r.c2, a.c2); }
   static HD bool is_zero(const E& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1) && fp_is_zero(a.c2); }
   static HD void zero(E& r) { fp_zero(r.c0); fp_zero(r.c1); fp_zero(r.c2); }
   static HD void one(E& r) { fp_one(r.c0); fp_zero(r.c1); fp_zero(r.c2); }
@@ -226,6 +230,7 @@ struct FieldFp2S {
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
   static HD void neg(E& r, const E& a) { fp_neg(r, a); }
+  static HD void half(E& r, const E& a) { fp_half(r, a); }   // component-wise: halving needs no exchange
   static HD bool is_zero(const E& a) {
     const uint32_t z = fp_is_zero(a) ? 1u : 0u;
     return (z & pair_swap_u32(z)) != 0;
@@ -317,6 +322,7 @@ struct FieldFp3S {
   static HD void add(E& r, const E& a, const E& b) { fp_add(r, a, b); }
   static HD void sub(E& r, const E& a, const E& b) { fp_sub(r, a, b); }
   static HD void neg(E& r, const E& a) { fp_neg(r, a); }
+  static HD void half(E& r, const E& a) { fp_half(r, a); }   // component-wise: halving needs no exchange
   static HD bool is_zero(const E& a) {
     const int lane = wave_lane(), g = lane - lane % 3;
     const uint32_t z = fp_is_zero(a) ? 1u : 0u;
@@ -390,6 +396,9 @@ template <> struct SplitOf<Mnt6G2> { using type = Mnt6G2S; };
 
 template <class F, class = void> struct has_sqr : std::false_type {};
 template <class F> struct has_sqr<F, std::enable_if_t<F::HAS_SQR>> : std::true_type {};
+// F::inv exists (base fields, lane-split fields); the one-lane extension fields go through the e_inv overloads of msm_kernels.hip.h
+template <class F, class = void> struct has_inv : std::false_type {};
+template <class F> struct has_inv<F, std::void_t<decltype(F::inv(std::declval<typename F::E&>(), std::declval<const typename F::E&>()))>> : std::true_type {};
 template <class F, class = void> struct has_lazy : std::false_type {};
 template <class F> struct has_lazy<F, std::enable_if_t<F::HAS_LAZY>> : std::true_type {};
 
@@ -515,6 +524,94 @@ HD void pt_vm(Proj<C>& P, const Proj<C>& Q, int pc) {
         break;
       case 36: P.Z = r; pc = 2; break;                           // Z1Z2, continue with the shared tail
       default: pc = PC_END; break;
+    }
+  }
+}
+
+// ---- the doubling chain of the table: modified Jacobian coordinates (round 5) ------------------------------------------------------
+// Row w of a point is 2^c times row w - 1: c doublings, (W - 1) c = 741 per point at c = 19 -- the whole cost of the table (8.5 G
+// products per 2^20 G1 points through the VM's projective doubling: eleven products, thirteen carried additions and the VM's
+// operand routing per doubling; 6.1 of the 9.0 s of a parameter load in round 4).  A chain of doublings wants the coordinates whose
+// doubling is cheapest, not the reference's: (X, Y, Z, W) with x = X / Z^2, y = Y / Z^3, W = a Z^4 (Cohen, Miyaji, Ono 1998), taken
+// up to the scaling (X, Y, Z, W) ~ (X / 4, Y / 8, Z / 2, W / 16), which removes the factors 4 and 8 of the textbook formulas:
+//     XX = X^2, YY = Y^2, S = X YY, Y4 = YY^2, H = (3 XX + W) / 2,
+//     X' = H^2 - 2 S,   Y' = H (S - X') - Y4,   Z' = Y Z,   W' = Y4 W                               4 products + 4 squarings,
+// one halving (fp_half) and five additions.  Only the AFFINE rows leave the kernel (x = X / Z^2, y = Y / Z^3 with one inversion per
+// point over all its windows), and an affine point has one representation: the table holds the same group elements as before.
+// Base fields: straight-line, the dedicated squarer, and the additions limb-wise without carries into the signed multiplier
+// (fp753.hip.h, "lazy arithmetic"; tools/host_jac_check.cpp runs chains of it on the CPU against the host field, limb ranges asserted) -- ranges, with p / R' = 0.1106 and inputs X, Y, Z, W in [0, 2p) on normalised limbs:
+//     XX, YY < 1.45p;  S < 1.32p;  Y4 < 1.24p;  3 XX + W < 6.35p on limbs < 2^30  ->  H < 3.68p, normalised limbs;
+//     H^2 < 2.51p;  H^2 - 2 S in (-2.64p, 2.51p), limbs in (-2^29, 2^28)  ->  X' = fp_norm(..) in [0.49p, 1.51p);
+//     S - X' in (-1.51p, 0.83p), |limbs| < 2^28;  H (S - X') in (-0.62p, 1.62p);  .. - Y4 in (-1.86p, 1.62p)  ->  Y' = fp_norm(..);
+//     Z' < 1.45p;  W' < 1.28p.
+// Every other field runs the same formulas through ONE instance of its multiplier in a step loop (eight fused lane-split products
+// written out would be 160 KB of code) with its own carried additions.  G2 runs on its lane-split configuration: two / three lanes
+// per point, as in the MSM's point kernels (the one-lane Karatsuba form spills kilobytes per lane).
+template <class F>
+struct Jac {
+  typename F::E X, Y, Z, W;
+};
+template <class C>
+HD void jac_dbl(Jac<typename C::F>& P) {
+  using F = typename C::F;
+  using E = typename F::E;
+  if constexpr (has_lazy<F>::value) {
+    constexpr int M = F::MOD;
+    E XX, YY, S, Y4, H, t, u;
+    fp_sqr(XX, P.X);
+    fp_sqr(YY, P.Y);
+    fp_mul(S, P.X, YY);
+    fp_sqr(Y4, YY);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) t.l[i] = 3u * XX.l[i] + P.W.l[i];
+    fp_half(H, t);
+    fp_sqr(t, H);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) u.l[i] = t.l[i] - 2u * S.l[i];
+    fp_mul(t, P.Y, P.Z);          // Z' (before Y is overwritten; P.X is dead from here on)
+    fp_norm(P.X, u);
+    P.Z = t;
+    fp_sub_raw(u, S, P.X);
+    fp_mul_s(t, H, u);
+    fp_sub_raw(u, t, Y4);
+    fp_norm(P.Y, u);
+    fp_mul(t, Y4, P.W);
+    P.W = t;
+    (void)M;
+  } else {
+    E XX, YY, S, Y4, H, a, b, r;   // (XX is dead after step 3 and keeps Y' from step 5 on)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int step = 0; step < 8; ++step) {
+      switch (step) {
+        case 0: a = P.X; b = P.X; break;
+        case 1: a = P.Y; b = P.Y; break;
+        case 2: a = P.X; b = YY; break;
+        case 3: a = YY; b = YY; break;
+        case 4: a = H; b = H; break;
+        case 5: a = H; b = S; break;     // S holds S - X' by then
+        case 6: a = P.Y; b = P.Z; break;
+        default: a = Y4; b = P.W; break;
+      }
+      F::mul(r, a, b);
+      switch (step) {
+        case 0: XX = r; break;
+        case 1: YY = r; break;
+        case 2: S = r; break;
+        case 3:
+          Y4 = r;
+          F::add(H, XX, XX); F::add(H, H, XX); F::add(H, H, P.W);
+          F::half(H, H);
+          break;
+        case 4:
+          F::sub(r, r, S); F::sub(P.X, r, S);
+          F::sub(S, S, P.X);
+          break;
+        case 5: F::sub(XX, r, Y4); break;    // Y', kept aside: step 6 still reads the old Y
+        case 6: P.Z = r; P.Y = XX; break;
+        default: P.W = r; break;
+      }
     }
   }
 }

@@ -44,6 +44,7 @@ struct DevState {
   hipEvent_t xfer_ev[MAX_DEVICES] = {};   // [dst]: "everything enqueued on this device's default stream so far" for a copy to dst
 };
 DevState g_devs[MAX_DEVICES];
+int g_peer[MAX_DEVICES][MAX_DEVICES];   // [device][peer]: 0 = not asked yet, else 1 + MNT753_PEER_*
 int g_ndev = 0;
 thread_local int t_cur_dev = 0;   // logical device the calling thread works on (mnt753_set_device)
 
@@ -205,16 +206,13 @@ int mnt753_init_devices(int n_devices) {
     return set_error(MNT753_EINVAL, "mnt753_init_devices: more devices requested than visible (MNT753_SHARE_DEVICE=1 maps them onto the visible ones)");
   for (int i = 0; i < n_devices; ++i)
     if (int rc = init_one(i, share ? i % count : i)) return rc;
-  // peer access for the scalar slices (device 0 -> the others); failing to enable it only makes hipMemcpyPeer stage through the host
-  for (int i = 1; i < n_devices; ++i) {
-    if (g_devs[i].phys == g_devs[0].phys) continue;
-    int can = 0;
-    if (hipDeviceCanAccessPeer(&can, g_devs[i].phys, g_devs[0].phys) == hipSuccess && can) {
-      (void)hipSetDevice(g_devs[i].phys);
-      (void)hipDeviceEnablePeerAccess(g_devs[0].phys, 0);
-    }
-    (void)hipGetLastError();
-  }
+  g_ndev = n_devices;
+  // peer access for EVERY ordered pair the sharded prover copies between (cuda_prover_piecewise.cu:24-34 has one device; here the
+  // transformed cb / cc travel 1 -> 0 and 2 -> 0, the slices of coefficients_for_H 0 -> g, operands of B:: vector calls any -> any):
+  // without it hipMemcpyPeerAsync stages through host memory.  Failing to enable a pair is not an error (the copy still works).
+  for (int a = 0; a < n_devices; ++a)
+    for (int b = 0; b < n_devices; ++b)
+      if (a != b) { int how = 0; (void)mnt753_enable_peer_access(a, b, &how); }
   g_ndev = n_devices;
   t_cur_dev = 0;
   HIP_TRY(hipSetDevice(g_devs[0].phys));
@@ -222,6 +220,29 @@ int mnt753_init_devices(int n_devices) {
 }
 
 int mnt753_device_count(void) { return g_ndev; }
+
+int mnt753_enable_peer_access(int device, int peer, int* how) {
+  if (device < 0 || device >= g_ndev || peer < 0 || peer >= g_ndev || !g_devs[device].ready || !g_devs[peer].ready)
+    return set_error(MNT753_EINVAL, "enable_peer_access: not an initialised device");
+  int& state = g_peer[device][peer];
+  if (state == 0) {
+    const int pa = g_devs[device].phys, pb = g_devs[peer].phys;
+    if (pa == pb) state = 1 + MNT753_PEER_SAME;
+    else {
+      int cur = -1, can = 0;
+      if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+      state = 1 + MNT753_PEER_STAGED;
+      if (hipDeviceCanAccessPeer(&can, pa, pb) == hipSuccess && can && hipSetDevice(pa) == hipSuccess) {
+        const hipError_t e = hipDeviceEnablePeerAccess(pb, 0);
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) state = 1 + MNT753_PEER_DIRECT;
+      }
+      (void)hipGetLastError();
+      if (cur >= 0) (void)hipSetDevice(cur);
+    }
+  }
+  if (how) *how = state - 1;
+  return 0;
+}
 
 int mnt753_set_device(int logical) {
   if (logical < 0 || logical >= g_ndev || !g_devs[logical].ready) return set_error(MNT753_EINVAL, "mnt753_set_device: not an initialised device");

@@ -98,7 +98,17 @@ int mnt753_exchange_points(const uint64_t* const* host_in, size_t words, uint64_
         if (phys[(size_t)g] == phys[(size_t)h]) return set_error(MNT753_ENODEV, "exchange_points: logical devices share a GPU (MNT753_SHARE_DEVICE): no RCCL communicator over them");
     std::string err;
     if (!g_ex.rccl.load(err)) return set_error(MNT753_ENODEV, err.c_str());
+    // whatever an earlier device count left behind goes first: communicators, streams, staging buffers (each on its own device)
     for (auto c : g_ex.comm) if (c) (void)g_ex.rccl.CommDestroy(c);
+    for (size_t g = 0; g < g_ex.stream.size(); ++g) {
+      if (g < g_ex.phys.size()) (void)hipSetDevice(g_ex.phys[g]);
+      if (g_ex.stream[g]) (void)hipStreamDestroy(g_ex.stream[g]);
+      if (g < g_ex.d_in.size() && g_ex.d_in[g]) (void)hipFree(g_ex.d_in[g]);
+      if (g < g_ex.d_out.size() && g_ex.d_out[g]) (void)hipFree(g_ex.d_out[g]);
+    }
+    (void)hipGetLastError();
+    g_ex.stream.clear(); g_ex.d_in.clear(); g_ex.d_out.clear();
+    g_ex.cap_words = 0; g_ex.n = 0;
     g_ex.comm.assign((size_t)n, nullptr);
     if (ncclResult_t r = g_ex.rccl.CommInitAll(g_ex.comm.data(), n, phys.data()); r != ncclSuccess) { g_ex.comm.clear(); g_ex.n = 0; return fail_nccl("ncclCommInitAll", r); }
     g_ex.phys = phys;
@@ -113,14 +123,17 @@ int mnt753_exchange_points(const uint64_t* const* host_in, size_t words, uint64_
     g_ex.n = n;
   }
   if (g_ex.cap_words < words) {
+    // grow: every pointer is nulled as it is freed and the capacity is zero until all of them are back, so a failing allocation
+    // leaves a state the next call rebuilds from instead of freed pointers it would free again or use
+    g_ex.cap_words = 0;
     for (int g = 0; g < n; ++g) {
       HIP_TRY(hipSetDevice(g_ex.phys[(size_t)g]));
-      if (g_ex.d_in[(size_t)g]) (void)hipFree(g_ex.d_in[(size_t)g]);
-      if (g_ex.d_out[(size_t)g]) (void)hipFree(g_ex.d_out[(size_t)g]);
+      if (g_ex.d_in[(size_t)g]) { (void)hipFree(g_ex.d_in[(size_t)g]); g_ex.d_in[(size_t)g] = nullptr; }
+      if (g_ex.d_out[(size_t)g]) { (void)hipFree(g_ex.d_out[(size_t)g]); g_ex.d_out[(size_t)g] = nullptr; }
       HIP_TRY(hipMalloc(&g_ex.d_in[(size_t)g], 8 * words));
       HIP_TRY(hipMalloc(&g_ex.d_out[(size_t)g], 8 * words * (size_t)n));
     }
-    if (g_ex.h_pin) (void)hipHostFree(g_ex.h_pin);
+    if (g_ex.h_pin) { (void)hipHostFree(g_ex.h_pin); g_ex.h_pin = nullptr; }
     HIP_TRY(hipHostMalloc(&g_ex.h_pin, 8 * words * (size_t)n * 2));
     g_ex.cap_words = words;
   }

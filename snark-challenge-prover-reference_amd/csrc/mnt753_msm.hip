@@ -2,7 +2,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_set>
 #include "common_host.hpp"
 #include "msm_api.hpp"
 #include "msm_types.hpp"
@@ -23,6 +25,10 @@ namespace {
 // scheduled ahead of its remaining workgroups.
 // (MNT753_G2_STREAM_PRIO=1, development: the G2 sets one level above the G1 ones, so that the longest MSM of a prove gets the wave
 // slots first and its latency-bound tail runs under the others' throughput phases)
+// live base sets: mnt753_msm_order_after lets one set wait for an event another set owns, so freeing a set must take its event out
+// of every set that still refers to it
+std::mutex g_sets_mu;
+std::unordered_set<mnt753_bases*> g_sets;
 hipError_t create_msm_stream(hipStream_t* s, int group) {
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; greatest = 0; }
@@ -50,6 +56,7 @@ int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_dev
   if (create_msm_stream(&b->own_stream, group) != hipSuccess) b->own_stream = nullptr;
   if (hipEventCreateWithFlags(&b->ev_dep, hipEventDisableTiming) != hipSuccess) b->ev_dep = nullptr;
   (void)hipGetLastError();
+  { std::lock_guard<std::mutex> l(g_sets_mu); g_sets.insert(b); }
   *out = b;
   return 0;
 }
@@ -58,6 +65,12 @@ int mnt753_bases_free(mnt753_bases* b) {
   if (!b) return 0;
   OnDevice on(b->device);
   if (b->pending && b->pending_n) (void)hipStreamSynchronize(b->pending_stream);   // never free buffers under a running MSM
+  {
+    std::lock_guard<std::mutex> l(g_sets_mu);
+    g_sets.erase(b);
+    for (mnt753_bases* o : g_sets)
+      if (o->after_owner == b) { o->after_ev = nullptr; o->after_owner = nullptr; }   // its event is about to be destroyed
+  }
   msm_free_workspace(b);
   if (b->d_aff) (void)hipFree(b->d_aff);
   if (b->d_inf) (void)hipFree(b->d_inf);
@@ -73,7 +86,12 @@ size_t mnt753_bases_size(const mnt753_bases* b) { return b ? b->n : 0; }
 int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first) {
   if (!b || !first || b == first) return set_error(MNT753_EINVAL, "msm_order_after: two different base sets");
   if (b->device != first->device) return set_error(MNT753_EINVAL, "msm_order_after: the two base sets live on different devices");
-  b->after_ev = first->ev[2];   // recorded behind the accumulate kernel of first's latest mnt753_msm_start (null before its first: no wait)
+  std::lock_guard<std::mutex> l(g_sets_mu);
+  if (!g_sets.count(const_cast<mnt753_bases*>(first)) || !g_sets.count(b)) return set_error(MNT753_EINVAL, "msm_order_after: not a live base set");
+  // first's event, recorded behind the accumulate kernel of its LATEST mnt753_msm_start at the time b starts (null before first's
+  // first start: no wait).  It stays first's: mnt753_bases_free(first) clears the reference, so b never waits on a destroyed event.
+  b->after_ev = first->ev[2];
+  b->after_owner = first;
   return 0;
 }
 

@@ -1,4 +1,5 @@
-// Test hooks of the C ABI: the device field layer exposed element-wise, so that tests/ can pin fp_mul / fp_add / fp_sub /
+// TEST INFRASTRUCTURE (libmnt753_hip_test.so, include/mnt753_hip_test.h) -- not linked into the product library.
+// Test hooks beside the C ABI: the device field layer exposed element-wise, so that tests/ can pin fp_mul / fp_add / fp_sub /
 // fp_inv / fp_neg / fp_canon / the wire conversions directly against the reference's golden field vectors
 // (tests/golden/field_A.bin, field_B.bin: minted from libff's Fp_model, fields/fp.tcc:161-186, 405-417, 491-508, 641-685)
 // instead of only through MSM / FFT results; the extension fields of G2 (one-lane Karatsuba forms and the lane-split forms the
@@ -9,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common_host.hpp"
+#include "../../include/mnt753_hip_test.h"
 #include "msm_kernels.hip.h"
 
 using namespace mnt753;
@@ -97,8 +99,6 @@ __device__ __forceinline__ void ext_store(uint32_t* wire, const typename F::E& a
     store_wire24(wire + 24 * lane_comp<F>(), w);
   }
 }
-template <class F, class = void> struct has_inv : std::false_type {};
-template <class F> struct has_inv<F, std::void_t<decltype(F::inv(std::declval<typename F::E&>(), std::declval<const typename F::E&>()))>> : std::true_type {};
 
 // op: 0 a*b, 1 a*a (through the multiplier the point kernels use), 2 a^-1, 3 a+b, 4 a-b, 5 -a, 6 is_zero(a - b) as 0 / 1 in word 0
 template <class F>

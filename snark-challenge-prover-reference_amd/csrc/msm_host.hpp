@@ -269,10 +269,19 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
     uint32_t *ztmp = nullptr, *ptmp = nullptr;
     HIP_TRY(hipMalloc(&ztmp, sizeof(uint32_t) * EW * tile * (size_t)pW));
     HIP_TRY(hipMalloc(&ptmp, sizeof(uint32_t) * EW * tile * (size_t)pW));
+    // the doubling chains run on the configuration the point kernels use: two / three lanes per point for G2
+    using CS = typename SplitOf<C>::type;
     for (size_t i0 = 0; i0 < n; i0 += tile) {
       const size_t cnt = std::min(tile, n - i0);
-      hipLaunchKernelGGL((k_precompute_windows<C>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, b->d_aff, b->d_inf, ztmp, ptmp, n,
-                         i0, cnt, pc, pW);
+      bool split = false;
+      if constexpr (!std::is_void<CS>::value) {
+        if (use_split_acc<C>()) {
+          split = true;
+          hipLaunchKernelGGL((k_precompute_windows<CS>), dim3(blocks_for<typename CS::F>(cnt)), dim3(256), 0, 0, b->d_aff, b->d_inf, ztmp, ptmp, n, i0, cnt, pc, pW);
+        }
+      }
+      if (!split)
+        hipLaunchKernelGGL((k_precompute_windows<C>), dim3(blocks_for<typename C::F>(cnt)), dim3(256), 0, 0, b->d_aff, b->d_inf, ztmp, ptmp, n, i0, cnt, pc, pW);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -808,7 +817,7 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   }
   HIP_TRY(hipEventRecord(b->ev[1], st));
   // mnt753_msm_order_after: the sort above ran whenever it could; the kernels that fill the chip start once the other set's have ended
-  if (b->after_ev) { HIP_TRY(hipStreamWaitEvent(st, b->after_ev, 0)); b->after_ev = nullptr; }
+  if (b->after_ev) { HIP_TRY(hipStreamWaitEvent(st, b->after_ev, 0)); b->after_ev = nullptr; b->after_owner = nullptr; }
   // point stages: with the lane-split configuration of the group (Fq2: two lanes per point, Fq3: three) when it has
   // one, otherwise one lane per point.  MNT753_MSM_ACC=vm forces one lane.
   uint32_t* cur = nullptr;

@@ -631,6 +631,13 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
 // cancel: the slot gets the fixed point D (`gen`, the group generator) and fix_count[bucket] is incremented -- k_pair_fix
 // subtracts fix_count * D from those buckets after the edge merge, so the accumulate kernel never sees an empty slot.
 constexpr uint32_t ENTRY_EMPTY = 0xffffffffu;
+// timing experiment only (results wrong by design): the first level's table rows folded into a span of 2^k rows, to measure what
+// the width of the gathered range costs (tools/experiments/README.md, profiles/r05/level1_row_span.txt)
+#ifdef MNT753_EXP_ROW_MASK
+#define PAIR_ROW(r) ((r) & (uint32_t)(MNT753_EXP_ROW_MASK))
+#else
+#define PAIR_ROW(r) (r)
+#endif
 enum : uint32_t { PK_ADD = 0, PK_DBL = 1, PK_CANCEL = 2, PK_SINGLE = 3, PK_EMPTY = 4 };
 
 // b + (negate ? -y : y) without a separate negation: the subtrahend / addend is chosen limb-wise
@@ -924,7 +931,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       const uint32_t rs = i / rq, q = i - rs * rq;       // row slot = point * NS + slot
       const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
       const uint32_t e = ent_img[buf * 128u + 2u * s + p];
-      const uint32_t r = e == ENTRY_EMPTY ? 0u : (e & 0x7fffffffu);
+      const uint32_t r = e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu);
       glds16(table + (size_t)r * RQ + q, im + 64u * k);
     } else {
       const uint32_t o = min(it * NLe + (lane_on ? t : t0w), S - 1u);
@@ -948,7 +955,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     const uint32_t rs = i / RQ, q = i - rs * RQ;
     const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
     const uint32_t e = ent_img[buf * 128u + 2u * s + p];
-    return (e == ENTRY_EMPTY ? 0u : (e & 0x7fffffffu)) * RQ + q;
+    return (e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu)) * RQ + q;
   };
   auto load_row_offsets = [=](uint32_t buf, auto xonly_c, uint32_t (&off)[ROW_PIECES]) __attribute__((always_inline)) {
     constexpr bool xonly = decltype(xonly_c)::value;
@@ -961,7 +968,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       const uint32_t rs = i / rq, q = i - rs * rq;
       const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
       const uint32_t e = ent_img[buf * 128u + 2u * s + p];
-      const uint32_t r = e == ENTRY_EMPTY ? 0u : (e & 0x7fffffffu);
+      const uint32_t r = e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu);
       off[k] = r * RQ + q;
     }
   };
@@ -1054,8 +1061,8 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
         // same x: equal points (doubling, denominator 2y) or opposite points (cancellation, take 1).  Rare: plain loads.
         if constexpr (first) {
           const uint2 e = reinterpret_cast<const uint2*>(entries)[o];
-          fp_load(y1, src_rows + (size_t)(e.x & 0x7fffffffu) * AW + EW + cw);
-          fp_load(y2, src_rows + (size_t)(e.y & 0x7fffffffu) * AW + EW + cw);
+          fp_load(y1, src_rows + (size_t)PAIR_ROW(e.x & 0x7fffffffu) * AW + EW + cw);
+          fp_load(y2, src_rows + (size_t)PAIR_ROW(e.y & 0x7fffffffu) * AW + EW + cw);
         } else if constexpr (IRR) {
           const uint32_t s1 = sw_cur & 0x7fffffffu, s2 = s1 + 1u;
           (void)fp_load_blk(y1, src_planes + (2 + (s1 & 1u)) * src_stride, (s1 >> 1) * LN + comp);
@@ -1910,8 +1917,9 @@ __device__ void e_inv(Fp3E<M>& r, const Fp3E<M>& x, FieldFp3<M, NR>*) {   // fp3
   fp_mul(r.c0, t6, c0); fp_mul(r.c1, t6, c1); fp_mul(r.c2, t6, c2);
 }
 
-// one lane per point of a tile [i0, i0 + count):  table rows for w >= 1; row 0 is the base itself (d_aff).
-//   ztmp: [W][count] E  (Z_w, then reused),  ptmp: [W][count] E (prefix products)
+// (the doubling chain of the table runs in modified Jacobian coordinates: jac_dbl, curve753.hip.h)
+// One logical lane (1, 2 or 3 threads, msm_kernels' lane-split convention) per point of a tile [i0, i0 + count): table rows for
+// w >= 1; row 0 is the base itself (d_aff).   ztmp: [W][count] E  (Z_w),  ptmp: [W][count] E (prefix products of the Z_w)
 template <class C>
 __global__ void __launch_bounds__(256, 1) k_precompute_windows(uint32_t* __restrict__ table, const uint8_t* __restrict__ inf,
                                                               uint32_t* __restrict__ ztmp, uint32_t* __restrict__ ptmp, size_t n_total,
@@ -1919,26 +1927,27 @@ __global__ void __launch_bounds__(256, 1) k_precompute_windows(uint32_t* __restr
   using F = typename C::F;
   using E = typename F::E;
   constexpr int EW = F::DEG * FPS_WORDS;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= count) return;
+  const uint32_t tl = logical_lane<F>();
+  if (tl == 0xffffffffu || (size_t)tl >= count) return;   // (all threads of a logical lane leave together)
+  const size_t t = tl;
   const size_t i = i0 + t;
   if (inf[i]) return;   // identity bases never enter a bucket (their digits are forced to 0)
-  Proj<C> R, Q;
+  Jac<F> R;
   e_load<F>(R.X, table + i * aff_words<C>());
   e_load<F>(R.Y, table + i * aff_words<C>() + EW);
   F::one(R.Z);
-  pt_set_zero(Q);
-  // pass 1: R_w = 2^c R_{w-1} (projective); keep X, Y in the table row and Z in ztmp
+  C::coeff_a(R.W);
+  // pass 1: R_w = 2^c R_{w-1}; keep X, Y in the table row and Z in ztmp
 #pragma unroll 1
   for (int w = 1; w < W; ++w) {
 #pragma unroll 1
-    for (int k = 0; k < c; ++k) pt_vm<C, false>(R, Q, PC_DBL);
+    for (int k = 0; k < c; ++k) jac_dbl<C>(R);
     uint32_t* row = table + ((size_t)w * n_total + i) * aff_words<C>();
     e_store<F>(row, R.X);
     e_store<F>(row + EW, R.Y);
     e_store<F>(ztmp + ((size_t)w * count + t) * EW, R.Z);
   }
-  // pass 2: batch inversion of Z_1..Z_{W-1} (Montgomery's trick) and normalisation to affine
+  // pass 2: batch inversion of Z_1..Z_{W-1} (Montgomery's trick) and normalisation to affine: x = X / Z^2, y = Y / Z^3
   E pre, z, inv, zi, x, y, tmp;
   F::one(pre);
 #pragma unroll 1
@@ -1948,19 +1957,37 @@ __global__ void __launch_bounds__(256, 1) k_precompute_windows(uint32_t* __restr
     F::mul(tmp, pre, z);
     pre = tmp;
   }
-  e_inv(inv, pre, (F*)nullptr);
+  if constexpr (has_inv<F>::value) F::inv(inv, pre); else e_inv(inv, pre, (F*)nullptr);
 #pragma unroll 1
   for (int w = W - 1; w >= 1; --w) {
     e_load<F>(tmp, ptmp + ((size_t)w * count + t) * EW);
     e_load<F>(z, ztmp + ((size_t)w * count + t) * EW);
-    F::mul(zi, inv, tmp);                                      // 1 / Z_w
-    F::mul(tmp, inv, z);
-    inv = tmp;
     uint32_t* row = table + ((size_t)w * n_total + i) * aff_words<C>();
     e_load<F>(x, row);
     e_load<F>(y, row + EW);
-    F::mul(tmp, x, zi); e_store<F>(row, tmp);
-    F::mul(tmp, y, zi); e_store<F>(row + EW, tmp);
+    // five products through one multiplier instance: 1 / Z_w, the running inverse, 1 / Z^2, x, 1 / Z^3, y
+    E zi2;
+#pragma nounroll
+    for (int step = 0; step < 6; ++step) {
+      E a, b, r;
+      switch (step) {
+        case 0: a = inv; b = tmp; break;    // 1 / Z_w
+        case 1: a = inv; b = z; break;      // inverse of the shorter prefix
+        case 2: a = zi; b = zi; break;
+        case 3: a = x; b = zi2; break;
+        case 4: a = zi2; b = zi; break;
+        default: a = y; b = zi; break;      // zi holds 1 / Z^3 by then
+      }
+      F::mul(r, a, b);
+      switch (step) {
+        case 0: zi = r; break;
+        case 1: inv = r; break;
+        case 2: zi2 = r; break;
+        case 3: e_store<F>(row, r); break;
+        case 4: zi = r; break;
+        default: e_store<F>(row + EW, r); break;
+      }
+    }
   }
 }
 

@@ -58,5 +58,6 @@ struct mnt753_bases {
   hipStream_t pending_stream = nullptr, own_stream = nullptr;
   hipEvent_t ev_dep = nullptr;
   hipEvent_t after_ev = nullptr;   // mnt753_msm_order_after: the point kernels of the next MSM wait for this event (another set's accumulate)
+  const mnt753_bases* after_owner = nullptr;   // the set that owns after_ev: mnt753_bases_free of that set clears both
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };

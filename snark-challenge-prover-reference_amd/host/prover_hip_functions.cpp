@@ -602,8 +602,22 @@ template <int CURVE> static void resolve(typename mnt753_hip_impl<CURVE>::G2* p)
 template <int CURVE> void HIP_B::use_devices(int n) { g_n_devices = n < 1 ? 1 : n; }
 template <int CURVE> void HIP_B::init_public_params() {
   if (g_n_devices == 0) { const char* e = getenv("MNT753_GPUS"); g_n_devices = e && atoi(e) > 0 ? atoi(e) : 1; }
-  if (g_n_devices > 1) check(mnt753_init_devices(g_n_devices), "mnt753_init_devices");
-  else check(mnt753_init(0), "mnt753_init");
+  if (g_n_devices > 1) {
+    check(mnt753_init_devices(g_n_devices), "mnt753_init_devices");
+    // every ordered pair the sharded prover copies between: cb / cc 1 -> 0 and 2 -> 0, slices of coefficients_for_H 0 -> g, operands
+    // of the B:: vector calls between any two (operand_on).  The destination's copy engine reads the source's memory; without peer
+    // access the copy stages through the host.  One line per pair under MNT753_TRACE=1.
+    const char* e = getenv("MNT753_TRACE");
+    const bool trace = e && atoi(e);
+    static const char* const names[] = {"same GPU (logical devices share it)", "direct (peer access enabled)", "staged through host memory (no peer access)"};
+    for (int a = 0; a < g_n_devices; ++a)
+      for (int b = 0; b < g_n_devices; ++b) {
+        if (a == b) continue;
+        int how = MNT753_PEER_STAGED;
+        check(mnt753_enable_peer_access(a, b, &how), "mnt753_enable_peer_access");
+        if (trace) fprintf(stderr, "mnt753: device %d reads device %d: %s\n", a, b, names[how >= 0 && how <= 2 ? how : 2]);
+      }
+  } else check(mnt753_init(0), "mnt753_init");
 }
 
 template <int CURVE> void HIP_B::print_G1(G1* a) {

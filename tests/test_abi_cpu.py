@@ -14,10 +14,15 @@ import oracle_lib as O
 ROOT = O.ROOT
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "mnt753_hip.h")).read()
+def header_symbols(name="mnt753_hip.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mnt753_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("mnt753_")}
 
 
 def test_library_exports_every_declared_symbol(pkg):
@@ -27,6 +32,21 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/mnt753_hip.h but not exported"
     pkg.lib()   # the ctypes signature table resolves as well
+
+
+def test_product_and_test_library_are_separate(pkg):
+    """Round 5: the product library exports exactly what include/mnt753_hip.h declares -- no test hook, no synthetic base
+    generator; those are libmnt753_hip_test.so (include/mnt753_hip_test.h), which needs the product, never the other way round."""
+    prod, test = exported(pkg.lib_path()), exported(pkg.api.test_lib_path())
+    assert prod == set(header_symbols()), sorted(prod ^ set(header_symbols()))
+    assert test == set(header_symbols("mnt753_hip_test.h")), sorted(test)
+    assert not any(s.startswith("mnt753_test_") or s in ("mnt753_synth_points", "mnt753_synth_expected_msm") for s in prod)
+    needed = lambda p: subprocess.run(["readelf", "-d", p], capture_output=True, text=True, check=True).stdout
+    assert "libmnt753_hip.so" in needed(pkg.api.test_lib_path())
+    assert "libmnt753_hip_test" not in needed(pkg.lib_path())
+    assert "libmnt753_hip_test" not in needed(os.path.join(ROOT, "snark-challenge-prover-reference_amd", "main_hip"))
+    assert "oracle" not in needed(pkg.lib_path()) and "oracle" not in needed(pkg.api.test_lib_path())
+    pkg.api.test_lib()
 
 
 def test_sizes(pkg):
@@ -122,6 +142,17 @@ def test_device_field_arithmetic_compiled_for_the_host(tmp_path):
     subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), src], check=True, timeout=600)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_window_table_doubling_compiled_for_the_host(tmp_path):
+    """Round 5: the doubling chain of the window table runs in modified Jacobian coordinates (jac_dbl, curve753.hip.h), not through
+    the reference's projective dbl() -- only affine rows leave the kernel.  On the CPU: 2P against libff's own vectors
+    (mnt4753_g1.cpp:315-346, mnt4753_g2.cpp:331-362, mnt6753_g2.cpp:337-368 -> tests/golden/group_*.bin), chains of 45 doublings against
+    the host field, and the limb ranges the lazy base-field form states, asserted after every doubling."""
+    exe = tmp_path / "host_jac_check"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tools", "host_jac_check.cpp")], check=True, timeout=600)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.skipif(not os.path.isfile("/root/reference/cuda_prover_piecewise.cu"), reason="needs the reference tree (build container only)")

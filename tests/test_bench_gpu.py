@@ -16,8 +16,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_multi_rank_flow(gpu, world):
     env = dict(os.environ, BENCH_SHARE_GPU="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-n", "13"],
-                       capture_output=True, text=True, env=env, timeout=900)
+    # --prove-log2-d 14 10: the prove legs at the reference generator's `fast` sizes, for which tests/golden/oracle_hashes.json holds the
+    # reference's proofs (the driver's run uses the metric's own 2^20 / 2^15)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-n", "13",
+                        "--prove-log2-d", "14", "10"], capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -29,13 +31,24 @@ def test_bench_multi_rank_flow(gpu, world):
     assert j["value"] > 0 and j["weak"]["value"] > 0 and j["unit"] == "points/s"
     for key in ("metric", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
         assert key in j
+    # round 5: the prove at N GPUs is in the line -- main_hip --gpus N started by rank 0 before any rank touched a GPU (libsnark/main.cpp:203-270
+    # is the window, multiexp.tcc:417-440 the sharding), its bytes are the reference's, also from a cold process and with the fold over RCCL requested
+    minted = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_hashes.json")))
+    for key, name in (("prove", "MNT4753_2p14"), ("prove_mnt6753", "MNT6753_2p10")):
+        pr = j[key]
+        assert pr["n_gpus"] == world and pr["parity_ok"] is True, pr
+        assert pr["sha256"] == minted[name]["output_sha256"] and pr["input_to_output_s"] > 0
+        assert pr["cold_process"]["same_bytes"] is True and pr["cold_process"]["input_to_output_s"] > 0
+        assert pr["fold_rccl"]["same_bytes"] is True and pr["fold_rccl"]["folded"].startswith("on the host")   # logical devices share the GPU here
 
 
 def test_bench_single_gpu_contract_small(gpu):
     """The N = 1 line at a small size: every field of the contract, no prove / extras legs (those need the 2^20 workload)."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "13", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "13", "--no-cpu-baseline",
+                        "--prove-log2-d", "14", "10"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["parity_ok"] is True
+    assert j["n_gpus"] == 1 and j["scaling"] == "strong" and j["parity_ok"] is True   # the N = 1 point of the strong series (one 2^20 array at every N)
+    assert j["prove"]["n_gpus"] == 1 and j["prove"]["parity_ok"] is True and j["prove"]["cold_process"]["same_bytes"] is True
+    assert j["prove"]["cold_process"]["input_to_output_s"] > 0 and j["prove"]["input_to_output_s"] > 0
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])

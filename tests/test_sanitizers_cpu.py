@@ -61,6 +61,26 @@ def test_compute_h_spread_over_devices_clean_under_sanitizers(san, kind, tmp_pat
                 assert f"{n_dev} devices" in r.stderr, r.stderr[-800:]
 
 
+def test_peer_access_requested_for_every_ordered_pair(san, tmp_path):
+    """Round 5: the transformed cb / cc travel 1 -> 0 and 2 -> 0, the slices of coefficients_for_H 0 -> g and operands of B:: vector
+    calls between any two devices; the wrapper asks the C ABI for peer access for EVERY ordered pair of its devices (the stub records
+    each request) and says per pair what it got (cuda_prover_piecewise.cu:24-34 keeps everything on one device: nothing to ask there)."""
+    params, inp, _ = G.e2e_paths(1)
+    out = str(tmp_path / "o")
+    for n_dev in range(2, 9):
+        env = dict(os.environ, MNT753_TRACE="1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+        r = subprocess.run([san["asan"], "MNT6753", "compute", params, inp, out, "--gpus", str(n_dev)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr, r.stderr[-3000:]
+        for a in range(n_dev):
+            for b in range(n_dev):
+                if a != b:
+                    assert f"stub: peer access requested {a} -> {b}\n" in r.stderr, (n_dev, a, b)
+                    assert f"mnt753: device {a} reads device {b}: same GPU" in r.stderr, (n_dev, a, b)
+        assert r.stderr.count("stub: peer access requested") == n_dev * (n_dev - 1)
+    r = subprocess.run([san["asan"], "MNT6753", "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_TRACE="1"), timeout=600)
+    assert r.returncode == 0 and "peer access" not in r.stderr
+
+
 @pytest.mark.parametrize("kind", ["asan", "tsan"])
 def test_fold_over_the_exchange_clean_under_sanitizers(san, kind, tmp_path):
     """--fold rccl: the partial points of every sharded multiexp go through mnt753_exchange_points (the stub copies them; with

@@ -10,7 +10,7 @@ mkdir -p $D
 OBJS=""
 for o in build/*.o; do
   b=$(basename $o .o)
-  case " $SRCS " in *" $b.hip "*) ;; *) case $b in *_t) ;; *) OBJS="$OBJS $o";; esac;; esac
+  case " $SRCS " in *" $b.hip "*) ;; *) case $b in *_t|mnt753_testhooks|mnt753_synth_points) ;; *) OBJS="$OBJS $o";; esac;; esac
 done
 for s in $SRCS; do
   b=$(basename $s .hip)
@@ -18,5 +18,5 @@ for s in $SRCS; do
 done
 wait
 for s in $SRCS; do OBJS="$OBJS $D/$(basename $s .hip).o"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libmnt753_hip.so $OBJS
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libmnt753_hip.so -o $D/libmnt753_hip.so $OBJS -ldl
 echo "built $D/libmnt753_hip.so"
