@@ -148,11 +148,6 @@ int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first);
 
 /* window size override (0 = automatic); returns previous value.  Tuning knob, not part of the reference. */
 int mnt753_msm_set_window_bits(int c);
-/* Compute units the long-running point kernels of an MSM are sized for (8 .. 256, default 256 = the whole MI355X); returns the
- * previous value.  A prover that runs the five MSMs of a proof concurrently (cuda_prover_piecewise.cu:71-81) sets 240: the two CUs
- * per XCD that stay free run the latency-bound phases of the other MSMs (sort, edge merge, narrow reduction steps) and the NTT
- * passes of compute_H underneath the accumulation phases.  Tuning knob, not part of the reference. */
-int mnt753_msm_set_point_cus(int cus);
 /* time of the last mnt753_msm call's kernels in milliseconds (HIP events on the launch stream):
  * index 0 = total, 1 = digits+sort, 2 = bucket accumulation kernel, 3 = bucket reduction, 4 = host tail */
 int mnt753_msm_last_timing(float out_ms[5]);

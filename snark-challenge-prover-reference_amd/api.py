@@ -64,7 +64,6 @@ def lib():
         "mnt753_msm_start": (i, [vp, sz, vp, i, sz, vp]),
         "mnt753_msm_finish": (i, [vp, u64p]),
         "mnt753_msm_set_window_bits": (i, [i]),
-        "mnt753_msm_set_point_cus": (i, [i]),
         "mnt753_msm_order_after": (i, [vp, vp]),
         "mnt753_msm_last_timing": (i, [C.POINTER(C.c_float)]),
         "mnt753_msm_last_plan": (i, [C.POINTER(C.c_int)]),

@@ -165,17 +165,15 @@ struct FieldFp3 {
 // that of a base-field element, so a G2 point operation needs the registers of a G1 one (the one-lane Fq2 VM keeps
 // ~950 dwords live and spills 1.7 KB per lane to scratch).  A product is
 //      even lane:  c0 = x0*y0 + (NR*x1)*y1        odd lane:  c1 = x1*y0 + x0*y1
-// i.e. ONE fp_mul2 per lane; the partner's operands arrive through DPP quad_perm [1,0,3,2] (v_mov_b32_dpp, no LDS).
+// i.e. ONE fp_mul2 per lane; the partner's operands arrive through ds_bpermute (the LDS crossbar, no LDS memory).
 // Both lanes of a pair always follow the same control flow (same sorted entries, same program counter).
 // Additions, subtractions and negations are component-wise and need no exchange.
 // ------------------------------------------------------------------------------------------
 HD uint32_t pair_swap_u32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#if defined(MNT753_PAIR_DPP)
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
-#else
+  // (a DPP quad_perm [1,0,3,2] move was 4 % faster in the accumulate kernel and made k_bucket_reduce<Mnt4G2S> fault or miscompute at
+  // 2^16..2^19 points -- DESIGN.md 4.2, finding 3; the exchange is ds_bpermute everywhere, the build switch left the source in round 5)
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u) ^ 1u) << 2), (int)v);
-#endif
 #else
   return v;   // host builds only need this to compile
 #endif

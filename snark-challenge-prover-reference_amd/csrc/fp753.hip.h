@@ -36,118 +36,15 @@ struct Fp {
   uint32_t l[NL];
 };
 
-// ---- Montgomery product: one level of subtractive Karatsuba on the product half --------------------------------------------
-// a = a0 + a1 B, b = b0 + b1 B with B = 2^(14 * 28) (14 + 13 limbs):
-//     a b = a0 b0 + [(a0 - a1)(b1 - b0) + a0 b0 + a1 b1] B + a1 b1 B^2
-// 196 + 169 + 196 = 561 multiply-adds instead of 729 (the middle product has signed factors: v_mad_i64_i32); the Montgomery
-// reduction half (729) is unchanged.  Column k of the product is assembled on the fly from three fresh column sums --
-//     lo_k = (a0 b0)_k,   hi_(k-14) = (a1 b1)_(k-14),   md_(k-14) = ((a0 - a1)(b1 - b0))_(k-14)
-// plus F[k] = lo_(k-14) + hi_(k-28), a 14-entry window of 64-bit sums that every lo / hi column feeds once more 14 columns later.
-// All sums are exact modulo 2^64 and the assembled column equals the schoolbook column, so the bounds of the schoolbook product
-// hold unchanged (27 |a_i| |b_j| + 27 2^56 < 2^63 for signed limbs).  Measured on MI355X (tools/experiments/mul_variants.hip,
-// profiles/r03/mul_variants_mi355x.txt): 21.4 G products/s at one wave per SIMD against 18.7 for the schoolbook product scanning
-// (+14 %; at one wave a multiply-add issues every ~5.9 cycles, an add every 4, and the column sums no longer hang on the carry of
-// the reduction), 23.7 against 22.5 at four waves.  In the product's kernels that gain does NOT arrive (same-box A/B, round 3,
-// profiles/r03/ab_karatsuba.txt): the 14-entry window and the operand differences cost ~56 more live registers in kernels that
-// already park 200+ values in AGPRs -- G1 accumulation phase 22.8 -> 22.4 ms, bucket reduction 2.04 -> 2.25 ms (k_reduce_step_line
-// starts to spill), i.e. nothing; the fused two- / three-product multipliers of the lane-split fields spill 1-2 KB per lane with it
-// and the G2 MSM ran 18x slower.  So the schoolbook product scanning stays the default and this stays a build option for the single
-// product (-DMNT753_KARATSUBA=1), kept correct by tools/host_fp_check.cpp.
-#ifndef MNT753_KARATSUBA
-#define MNT753_KARATSUBA 0
-#endif
-constexpr int KH = 14, KL = NL - KH;   // limbs of the low / high half
-// AL / BL: limb types of the operands as the multiply-add sees them (uint32_t: v_mad_u64_u32, int32_t: v_mad_i64_i32).
-// N products are summed under ONE reduction (the fused multipliers of the lane-split extension fields: N = 2, 3).
-template <int M, int N, class AL, class BL>
-HD void fp_mulN_karatsuba(uint32_t (&r)[NL], const AL* const (&a)[N], const BL* const (&b)[N]) {
-  typedef typename std::conditional<std::is_signed<AL>::value || std::is_signed<BL>::value, int64_t, uint64_t>::type P;   // product type of lo / hi
-  int32_t da[N][KH], db[N][KH];
-#pragma unroll
-  for (int p = 0; p < N; ++p) {
-#pragma unroll
-    for (int i = 0; i < KH; ++i) {
-      da[p][i] = (int32_t)a[p][i] - (i < KL ? (int32_t)a[p][KH + i] : 0);
-      db[p][i] = (i < KL ? (int32_t)b[p][KH + i] : 0) - (int32_t)b[p][i];
-    }
-  }
-  int64_t F[KH];
-#pragma unroll
-  for (int i = 0; i < KH; ++i) F[i] = 0;
-  int64_t carry = 0;
-  uint32_t m[NL];
-#pragma unroll
-  for (int k = 0; k < 2 * NL - 1; ++k) {
-    int64_t t = carry + F[k % KH];
-    int64_t fut = 0;
-    if (k < 2 * KH - 1) {                        // lo_k
-#pragma unroll
-      for (int p = 0; p < N; ++p) {
-        P s = 0;
-#pragma unroll
-        for (int i = (k < KH ? 0 : k - KH + 1); i <= (k < KH ? k : KH - 1); ++i) s += (P)a[p][i] * (P)b[p][k - i];
-        t += (int64_t)s; fut += (int64_t)s;
-      }
-    }
-    if (k >= KH && k - KH < 2 * KH - 1) {        // md_(k-14)
-      const int q = k - KH;
-#pragma unroll
-      for (int p = 0; p < N; ++p) {
-        int64_t s = 0;
-#pragma unroll
-        for (int i = (q < KH ? 0 : q - KH + 1); i <= (q < KH ? q : KH - 1); ++i) s += (int64_t)da[p][i] * db[p][q - i];
-        t += s;
-      }
-    }
-    if (k >= KH && k - KH < 2 * KL - 1) {        // hi_(k-14)
-      const int q = k - KH;
-#pragma unroll
-      for (int p = 0; p < N; ++p) {
-        P s = 0;
-#pragma unroll
-        for (int i = (q < KL ? 0 : q - KL + 1); i <= (q < KL ? q : KL - 1); ++i) s += (P)a[p][KH + i] * (P)b[p][KH + q - i];
-        t += (int64_t)s; fut += (int64_t)s;
-      }
-    }
-    F[k % KH] = fut;                             // lo_k + hi_(k-14): added again at column k + 14
-    uint64_t mp = 0;
-    if (k < NL) {
-#pragma unroll
-      for (int i = 0; i < k; ++i) mp += (uint64_t)m[i] * FPC[M].p[k - i];
-      t += (int64_t)mp;
-      m[k] = ((uint32_t)t * FPC[M].inv) & LMASK;
-      t += (int64_t)((uint64_t)m[k] * FPC[M].p[0]);
-    } else {
-#pragma unroll
-      for (int i = k - NL + 1; i < NL; ++i) mp += (uint64_t)m[i] * FPC[M].p[k - i];
-      t += (int64_t)mp;
-      r[k - NL] = (uint32_t)t & LMASK;
-    }
-    carry = t >> LB;
-  }
-  r[NL - 1] = (uint32_t)carry;
-}
-template <int M, class AL, class BL>
-HD void fp_mul_karatsuba(uint32_t (&r)[NL], const AL (&a)[NL], const BL (&b)[NL]) {
-  const AL* const pa[1] = {a};
-  const BL* const pb[1] = {b};
-  fp_mulN_karatsuba<M, 1>(r, pa, pb);
-}
-
+// (One level of subtractive Karatsuba on the product half -- 561 + 729 multiply-adds instead of 729 + 729 -- was built and measured in
+// round 3: +14 % in the microbenchmark at one wave per SIMD, nothing in the product's kernels, which have no registers for its 14-entry
+// window of 64-bit sums (profiles/r03/ab_karatsuba.txt, mul_variants_mi355x.txt).  It left the product in round 5; the formulation is
+// kept in tools/experiments/mul_variants.hip.)
 // ---- Montgomery product, radix 2^756, two interleaved column accumulators ------------------
 // r = a*b*2^-756 mod p, r < 2p provided a*b < 4p^2 (e.g. a,b < 2p; or a < 4p, b < p).
 // Limbs of a may be up to 2^29 (one un-normalised addition) -- the column bound still holds.
 template <int M>
 HD void fp_mul(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {
-#if MNT753_KARATSUBA
-  {
-    uint32_t out[NL];                    // (r may alias an operand)
-    fp_mul_karatsuba<M>(out, a.l, b.l);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) r.l[i] = out[i];
-    return;
-  }
-#endif
   uint64_t acc = 0, acc2 = 0;
   uint32_t m[NL];
 #pragma unroll
@@ -388,10 +285,6 @@ HD void fp_mul_s(Fp<M>& r, const Fp<M>& a_in, const Fp<M>& b_in) {
   struct { int32_t l[NL]; } a, b;
 #pragma unroll
   for (int i = 0; i < NL; ++i) { a.l[i] = fp_opaque_limb(a_in.l[i]); b.l[i] = fp_opaque_limb(b_in.l[i]); }
-#if MNT753_KARATSUBA
-  fp_mul_karatsuba<M>(r.l, a.l, b.l);
-  return;
-#endif
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
 #pragma unroll

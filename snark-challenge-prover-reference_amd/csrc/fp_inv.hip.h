@@ -9,7 +9,7 @@
 //
 // Number of steps: the original divstep (delta starts at 1) needs at most floor((49 d + 57) / 17) steps for inputs below
 // 2^d (Bernstein-Yang 2019, Theorem 11.2); d = 754 gives 2176 <= 78 * 28 = 2184.
-// Measured and NOT adopted (round 3, -DMNT753_INV_EARLY_EXIT=1): the half-delta variant (delta starts at 1/2, as in libsecp256k1's
+// Measured and NOT adopted (round 3; the build switch left the source in round 5): the half-delta variant (delta starts at 1/2, as in libsecp256k1's
 // modinv) run UNTIL g = 0 IN EVERY LANE OF THE WAVE -- once g is 0 a batch is the identity (transition matrix 2^28 I), so lanes
 // that are done early are unharmed and correctness rests on no step bound.  Random 753-bit inputs need 1520 steps on average and
 // 1536 as the maximum over the 64 lanes of a wave (simulation over 2560 inputs: at most 1544): 55-56 batches instead of 78.  Same
@@ -25,9 +25,6 @@
 
 namespace mnt753 {
 
-#ifndef MNT753_INV_EARLY_EXIT
-#define MNT753_INV_EARLY_EXIT 0   // 1: half-delta divsteps until g = 0 in every lane of the wave (measured, see above)
-#endif
 struct InvMat { int32_t u, v, q, r; };
 
 // 28 division steps on the low limbs; returns the new eta = -(delta + 1/2) (delta > 0 <=> eta < 0) and the transition matrix t with
@@ -44,11 +41,7 @@ HD int32_t inv_divsteps28(int32_t eta, uint32_t f0, uint32_t g0, InvMat& t) {
     const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;   // -f, -u, -v when delta > 0
     g += x & c2; q += y & c2; r += z & c2;
     c1 &= c2;                                     // swap case: delta > 0 and g odd
-#if MNT753_INV_EARLY_EXIT
-    eta = (int32_t)(((uint32_t)eta ^ c1) - 1u);   // eta = -(delta + 1/2): delta <- 1 - delta (swap: eta <- -eta - 2) or 1 + delta (eta - 1)
-#else
     eta = (int32_t)(((uint32_t)eta ^ c1) - (c1 + 1u));   // eta = -delta: delta <- 1 - delta (swap) or 1 + delta
-#endif
     f += g & c1; u += q & c1; v += r & c1;
     g >>= 1; u <<= 1; v <<= 1;
   }
@@ -108,18 +101,7 @@ HD void fp_inv_integer(uint32_t r[NL], const uint32_t a[NL]) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int it = 0; it < (MNT753_INV_EARLY_EXIT ? 400 : 78); ++it) {   // (the cap of 400 is never reached: five times the proven worst case)
-#if MNT753_INV_EARLY_EXIT
-    // done when g = 0 in every lane that is still running with this one (g: inner limbs unsigned, top limb signed -- zero iff all are)
-    uint32_t any = 0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) any |= (uint32_t)g[i];
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (!__any(any != 0)) break;
-#else
-    if (any == 0) break;
-#endif
-#endif
+  for (int it = 0; it < 78; ++it) {
     InvMat t;
     eta = inv_divsteps28(eta, (uint32_t)f[0], (uint32_t)g[0], t);
     inv_update_de<M>(d, e, t);

@@ -23,7 +23,7 @@ thread_local std::string t_last_error;
 // once per device at initialisation (outside any timed region) and reused under a mutex.  IO_LANES independent lanes (a stream, two
 // pinned 8 MB buffers and their events each): a large read is cut into IO_LANES contiguous parts that are read (pread) and copied
 // concurrently (opt-in, see mnt753_load_file_to_device).
-constexpr int IO_LANES = 4;
+constexpr int IO_LANES = 2;
 struct IoLane {
   hipStream_t stream = nullptr;
   void* buf[2] = {nullptr, nullptr};
@@ -59,12 +59,9 @@ int init_one(int logical, int phys) {
     size_t smax = 0, scur = 0;
     if (hipDeviceGetLimit(&smax, hipExtLimitScratchMax) == hipSuccess && hipDeviceGetLimit(&scur, hipExtLimitScratchCurrent) == hipSuccess &&
         smax > scur) {
-      size_t want = smax;
-      if (const char* e = getenv("MNT753_SCRATCH_LIMIT_MB")) want = (size_t)atoll(e) << 20;
-      if (want > smax) want = smax;
-      if (want > scur) (void)hipDeviceSetLimit(hipExtLimitScratchCurrent, want);
+      (void)hipDeviceSetLimit(hipExtLimitScratchCurrent, smax);
     }
-    if (getenv("MNT753_VERBOSE")) {
+    if (const char* e = getenv("MNT753_TRACE"); e && atoi(e) > 1) {   // MNT753_TRACE=2: initialisation details as well
       size_t now = 0; (void)hipDeviceGetLimit(&now, hipExtLimitScratchCurrent);
       fprintf(stderr, "mnt753: device %d (physical %d): scratch limit max %zu MB, was %zu MB, now %zu MB\n", logical, phys, smax >> 20, scur >> 20, now >> 20);
     }
@@ -377,11 +374,11 @@ int mnt753_load_file_to_device(const char* path, size_t file_offset, size_t byte
   // (403 MB: 21 -> 12 ms).  More lanes bring the 403 MB of a 2^20 input from 11-17 ms to 10-12; in round 3 the FIRST proof of a
   // process -- the reference's metric -- paid 5-30 ms for them, which was the first large copy of every lane's stream: the
   // initialisation sends both buffers of every lane over once since round 4, and two lanes are the default (first proof 0.1562 ->
-  // 0.1557 s median of six alternations, later proofs 0.1552 -> 0.1548: profiles/r04/prove_io_lanes.txt).  MNT753_IO_LANES=1..4.
-  static const int max_lanes = [] { const char* e = getenv("MNT753_IO_LANES"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > IO_LANES ? IO_LANES : v); }();
+  // 0.1557 s median of six alternations, later proofs 0.1552 -> 0.1548: profiles/r04/prove_io_lanes.txt).
+  constexpr int max_lanes = 2;
   const int lanes = bytes >= 4 * CHUNK ? max_lanes : 1;
   const size_t per = ((bytes / (size_t)lanes + CHUNK - 1) / CHUNK) * CHUNK;
-  int rcs[IO_LANES] = {0, 0, 0, 0};
+  int rcs[IO_LANES] = {0, 0};
   std::thread workers[IO_LANES];
   for (int l = 1; l < lanes; ++l) {
     const size_t lo = std::min(bytes, (size_t)l * per), hi = std::min(bytes, (size_t)(l + 1) * per);

@@ -15,7 +15,6 @@ float g_last_timing[5] = {0, 0, 0, 0, 0};
 int g_last_plan[4] = {0, 0, 0, 0};
 int g_last_pair_levels = 0;
 int g_last_irr_levels = 0;
-int g_point_cus = 256;
 }
 using namespace mnt753;
 
@@ -23,18 +22,16 @@ namespace {
 // MSM streams run at the lowest priority the device offers: an MSM is hundreds of milliseconds of throughput work,
 // and short kernels on the default stream (the NTTs of compute_H, launched while MSMs are in flight) should be
 // scheduled ahead of its remaining workgroups.
-// (MNT753_G2_STREAM_PRIO=1, development: the G2 sets one level above the G1 ones, so that the longest MSM of a prove gets the wave
-// slots first and its latency-bound tail runs under the others' throughput phases)
+// (The G2 sets one level above the G1 ones -- so that the longest MSM of a prove gets the wave slots first -- was measured in rounds 3
+// and 4 and gains nothing: workgroups are not pre-empted, profiles/r04/prove_point_cus_final.txt.)
 // live base sets: mnt753_msm_order_after lets one set wait for an event another set owns, so freeing a set must take its event out
 // of every set that still refers to it
 std::mutex g_sets_mu;
 std::unordered_set<mnt753_bases*> g_sets;
-hipError_t create_msm_stream(hipStream_t* s, int group) {
+hipError_t create_msm_stream(hipStream_t* s, int) {
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; greatest = 0; }
-  int prio = least;
-  if (group == MNT753_G2 && greatest < least && getenv("MNT753_G2_STREAM_PRIO") && atoi(getenv("MNT753_G2_STREAM_PRIO")) != 0) prio = least - 1;
-  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
 }
 }  // namespace
 
@@ -151,11 +148,6 @@ int mnt753_msm_set_window_bits(int c) {
   return old;
 }
 
-int mnt753_msm_set_point_cus(int cus) {
-  const int old = g_point_cus;
-  if (cus >= 8 && cus <= 256) g_point_cus = cus;
-  return old;
-}
 
 int mnt753_msm_last_timing(float out_ms[5]) {
   if (!out_ms) return set_error(MNT753_EINVAL, "msm_last_timing: null");

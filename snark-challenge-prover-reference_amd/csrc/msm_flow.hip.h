@@ -64,18 +64,15 @@ __device__ __forceinline__ FlowTask flow_task(int level, uint32_t m) {
   }
 }
 
-// Fq3 in the Karatsuba form (flow_add_k3 below): 32 lanes per addition, one BASE-field product per lane and round.  Build option
-// -DMNT753_FLOW_K3=0 keeps the fused three-product form on 16 lanes (55 us per addition against ~35).
-#ifndef MNT753_FLOW_K3
-#define MNT753_FLOW_K3 1
-#endif
+// Fq3 in the Karatsuba form (flow_add_k3 below): 32 lanes per addition, one BASE-field product per lane and round (the fused
+// three-product form on 16 lanes, which Fq2 uses with its two products, took 55 us per Fq3 addition against ~35)
 enum : uint32_t { FV_A = FV_COUNT, FV_RA, FV_Y3, FVK_COUNT };   // values the Karatsuba form materialises between its rounds
 template <class C>
 struct Flow {
   using F = typename C::F;                            // the ONE-lane field class of the group (FieldFp / FieldFp2 / FieldFp3)
   static_assert(F::LANES == 1, "the flow addition is instantiated with the one-lane configuration; its fallback picks the lane-split one");
   static constexpr int D = F::DEG, M = F::MOD;
-  static constexpr bool K3 = D == 3 && MNT753_FLOW_K3 != 0;
+  static constexpr bool K3 = D == 3;
   static constexpr uint32_t G = D == 1 ? 8u : (K3 ? 32u : 16u);   // lanes per addition: 5 D products in the widest round (5 x 6 pieces: K3)
   static constexpr uint32_t PER_WAVE = 64u / G;
   static constexpr uint32_t VAL_WORDS = (uint32_t)D * FPS_WORDS;

@@ -20,24 +20,19 @@
 
 using namespace mnt753;
 
-#ifndef MNT753_SORT_DEFAULT
-#define MNT753_SORT_DEFAULT SORT_PART
-#endif
 namespace mnt753 {
 extern int g_window_bits_override;
 extern float g_last_timing[5];
 extern int g_last_plan[4];
 extern int g_last_pair_levels;
 extern int g_last_irr_levels;
-extern int g_point_cus;
 }
 namespace {
 
 
 // window size: minimise  N*W (bucket adds)  +  ~3 * nb * W (reduction adds, incl. the k0*run tail)
 int pick_window_bits(size_t n) {
-  if (g_window_bits_override > 0) return g_window_bits_override;
-  if (const char* e = getenv("MNT753_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 22) return v; }
+  if (g_window_bits_override > 0) return g_window_bits_override;   // mnt753_msm_set_window_bits (tests)
   int best = 2; double best_cost = 1e300;
   for (int c = 2; c <= 20; ++c) {
     double W = (754 + c - 1) / c;
@@ -54,7 +49,6 @@ int pick_window_bits(size_t n) {
 //   2^20 points 25.0 / 24.3 / 25.0 / 26.2 ms at c = 18 / 19 / 20 / 21;  3 * 2^20: 66.0 / 64.1 / 62.3 / 62.0;  2^17: 5.3 ms at 18 against 6.2
 //   at 17;  MNT6753 2^15: 2.6 ms at 18 against 3.7 at 16.   Fq2 G2 2^20: 66.9 / 65.6 / 67.3 / 71.6 ms.
 int pick_precomp_bits(size_t n, double bucket_weight = 8.0, int min_c = 2) {
-  if (const char* e = getenv("MNT753_MSM_PRE_C")) { int v = atoi(e); if (v >= 2 && v <= 24) return v; }
   int best = min_c; double best_cost = 1e300;
   for (int c = min_c; c <= 22; ++c) {
     double W = (754 + c - 1) / c;
@@ -65,14 +59,11 @@ int pick_precomp_bits(size_t n, double bucket_weight = 8.0, int min_c = 2) {
 }
 
 // Compute units the long-running point kernels (pairing levels, accumulate) are sized for: one 256-thread workgroup per CU, every
-// workgroup alive for the whole kernel.  256 = the whole chip (a single MSM has nothing to share it with).  The prover runs five MSMs
-// on five streams, and their latency-bound phases (sort, edge merge, the narrow steps of the bucket reduction: a few workgroups, one
-// group addition deep) only overlap another MSM's point kernels if some CUs are NOT held by them: main_hip sizes the point kernels
-// for 240 (mnt753_msm_set_point_cus), which leaves two CUs per XCD to whatever else is ready.  MNT753_POINT_CUS overrides.
-inline uint32_t point_cus() {
-  if (const char* e = getenv("MNT753_POINT_CUS")) { int v = atoi(e); if (v >= 8 && v <= 256) return (uint32_t)v; }
-  return (uint32_t)g_point_cus;
-}
+// workgroup alive for the whole kernel, the whole chip.  (A smaller budget, leaving CUs to the latency-bound phases of the other MSMs
+// of a prove, was measured in rounds 3 and 4 at 240 / 224 / 208 CUs and gains nothing -- the prove is the energy of its kernels,
+// profiles/r04/prove_point_cus_final.txt -- and left the product in round 5.)
+constexpr uint32_t POINT_CUS = 256;
+inline uint32_t point_cus() { return POINT_CUS; }
 // logical lanes one round of those CUs holds: 256 threads per CU, 2 or 3 of them per point for the lane-split fields (21 triples
 // per wave, 84 per CU)
 inline uint32_t machine_lanes(int lanes_per_point) {
@@ -90,15 +81,15 @@ MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   p.n_buckets = p.n_sets * p.nb;
   // lanes: aim at `rounds` full rounds of the machine (256 CUs x 256 lanes, one wave per SIMD)
   const uint64_t entries = (uint64_t)p.W * n;
-  int rounds = entries < ((uint64_t)1 << 23) ? 1 : 2;   // small sets: fewer lanes = fewer edge pieces to combine (measured)
-  if (const char* e = getenv("MNT753_MSM_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 64) rounds = v; }
+  const int rounds = entries < ((uint64_t)1 << 23) ? 1 : 2;   // small sets: fewer lanes = fewer edge pieces to combine (measured)
   const uint64_t machine = machine_lanes(lanes_per_point);
   uint64_t lanes_target = machine * rounds;
   uint64_t T = (entries + lanes_target - 1) / lanes_target;
   // floor of entries per lane: a lane's walk is sequential (one mixed addition after the other, ~45 us each), so a small MSM is as
   // long as its T, while more lanes mean more edge pieces to merge (one addition per bucket that straddles a lane boundary).  Round 4
   // sweep with the tree merge (profiles/r04/small_msm_sweep.txt, MNT6753 G1): 2^12 points 1.96 / 1.62 / 1.61 ms at T = 16 / 8 / 4,
-  // 2^13 points 1.99 / 1.80 / 1.81; from 2^14 points on the natural T is above the floor.  MNT753_MSM_TMIN overrides (development).
+  // 2^13 points 1.99 / 1.80 / 1.81; from 2^14 points on the natural T is above the floor.  MNT753_MSM_TMIN overrides: the tests use it
+  // to make buckets span hundreds of lanes (trees ten levels deep in the edge merge).
   uint64_t t_min = 8;
   if (const char* e = getenv("MNT753_MSM_TMIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) t_min = (uint64_t)v; }
   if (T < t_min) T = t_min;
@@ -108,7 +99,6 @@ MsmPlan make_plan(size_t n, int pre_c, int lanes_per_point = 1) {
   // reduce chunk: ~one round of lanes
   uint32_t L = 1;
   while ((uint64_t)p.n_buckets / L > machine && L < p.nb) L <<= 1;
-  if (const char* e = getenv("MNT753_MSM_L")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v <= p.nb && (v & (v - 1)) == 0) L = v; }
   p.L = L;
   p.n_chunks = p.n_buckets / L;
   p.pair_levels = 0;   // filled in by the caller (plan_for): depends on the group and on the workspace the base set could get
@@ -124,20 +114,17 @@ namespace {
 template <class C>
 int proj_w() { return proj_words<C>(); }
 
-// Lane-split point kernels (FieldFp2S / FieldFp3S instantiations): default for the groups that have a split configuration
-// (G2 of both curves); MNT753_MSM_ACC=vm forces the one-lane-per-point kernels.
+// Lane-split point kernels (FieldFp2S / FieldFp3S instantiations) for the groups that have a split configuration (G2 of both
+// curves).  (The one-lane-per-point G2 kernels -- Karatsuba through one multiplier, 1.7-3.8 KB of scratch per lane, 1.8x slower -- left
+// the product in round 5; the test library still runs the one-lane forms of the group law against the reference's vectors.)
 template <class C>
-bool use_split_acc() {
-  if (std::is_void<typename SplitOf<C>::type>::value) return false;
-  if (const char* e = getenv("MNT753_MSM_ACC")) return strcmp(e, "vm") != 0;
-  return true;
-}
+constexpr bool use_split_acc() { return !std::is_void<typename SplitOf<C>::type>::value; }
 // threads per point in the point kernels of group C under the current settings
 template <class C>
 int point_lanes() {
   using CS = typename SplitOf<C>::type;
   if constexpr (std::is_void<CS>::value) return 1;
-  else return use_split_acc<C>() ? CS::F::LANES : 1;
+  else return CS::F::LANES;
 }
 void free_pair_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_pair_ws, b->d_fix, b->d_gen, b->d_pairpts[0], b->d_pairpts[1], b->d_sorted2, b->d_irr_offs[0], b->d_irr_offs[1], b->d_irr_src, b->d_irr_blocks};
@@ -152,7 +139,7 @@ void free_pair_ws(mnt753_bases* b) {
 void free_ws(mnt753_bases* b) {
   void* ptrs[] = {b->d_rank, b->d_digits, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, b->d_buckets,
                   b->d_edges, b->d_edge_bucket, b->d_edge_tmp, b->d_edge_flags, b->d_part_a, b->d_part_b, b->d_tmp, b->d_wire_out, b->d_scalars_stage,
-                  b->d_keys_out, b->d_vals_out, b->d_dense, b->d_sort_tmp, b->d_part_ws};
+                  b->d_keys_out, b->d_vals_out, b->d_part_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   free_pair_ws(b);
   if (b->h_wire_out) (void)hipHostFree(b->h_wire_out);
@@ -160,20 +147,20 @@ void free_ws(mnt753_bases* b) {
   b->d_edge_tmp = b->d_edge_flags = nullptr;
   b->d_sorted = b->d_buckets = b->d_edges = b->d_edge_bucket = b->d_part_a = b->d_part_b = b->d_tmp = b->d_wire_out = nullptr;
   b->h_wire_out = nullptr; b->d_scalars_stage = nullptr;
-  b->d_keys_out = b->d_vals_out = b->d_dense = nullptr; b->d_sort_tmp = nullptr; b->sort_tmp_bytes = 0; b->d_part_ws = nullptr;
+  b->d_keys_out = b->d_vals_out = nullptr; b->d_part_ws = nullptr;
   b->ws_n = 0;
   b->sorted_cap = 0;
 }
 
-// Sort stage from 2^22 entries on: the pairs go through a device-wide sort instead of the histogram-atomic counting sort (below that
-// its handful of launches cost more than the atomics it saves).  Two of them (msm_sort.hip): the hand-written two-level counting
-// sort ("part", round 3) and rocPRIM's radix sort ("radix", round 2).  MNT753_MSM_SORT=atomic / radix / part overrides.
-enum SortMode { SORT_ATOMIC = 0, SORT_RADIX = 1, SORT_PART = 2 };
+// Sort stage from 2^22 entries on: the hand-written two-level counting sort of msm_sort.hip instead of the histogram-atomic counting
+// sort (below that its handful of launches cost more than the atomics it saves).  MNT753_MSM_SORT=atomic / part overrides (the tests
+// run both stages on small and large inputs).  (rocPRIM's radix sort, the stage of round 2 -- 1.33 ms against 0.92 -- left the product
+// in round 5.)
+enum SortMode { SORT_ATOMIC = 0, SORT_PART = 2 };
 inline SortMode sort_mode(uint64_t entries) {
-  if (const char* e = getenv("MNT753_MSM_SORT")) return !strcmp(e, "atomic") ? SORT_ATOMIC : (!strcmp(e, "radix") ? SORT_RADIX : SORT_PART);
-  return entries >= ((uint64_t)1 << 22) ? MNT753_SORT_DEFAULT : SORT_ATOMIC;
+  if (const char* e = getenv("MNT753_MSM_SORT")) return !strcmp(e, "atomic") ? SORT_ATOMIC : SORT_PART;
+  return entries >= ((uint64_t)1 << 22) ? SORT_PART : SORT_ATOMIC;
 }
-inline bool use_radix_sort(uint64_t entries) { return sort_mode(entries) != SORT_ATOMIC; }   // needs the (key, value) buffers
 template <class C>
 int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   // entries of the sorted list: every bucket padded to a multiple of 2^pair_levels
@@ -192,15 +179,13 @@ int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {
   HIP_TRY(hipMalloc(&b->d_total, sizeof(uint32_t) * 4));
   HIP_TRY(hipMalloc(&b->d_sorted, sizeof(uint32_t) * sorted_need));
   b->sorted_cap = sorted_need;
-  if (use_radix_sort((uint64_t)p.W * n)) {
-    // radix-sort variant of the sort stage: failing to get its buffers only falls back to the counting sort
-    b->sort_tmp_bytes = msm_sort_temp_bytes((size_t)p.W * n);
-    if (b->sort_tmp_bytes == 0 || hipMalloc(&b->d_keys_out, sizeof(uint32_t) * (size_t)p.W * n) != hipSuccess ||
-        hipMalloc(&b->d_vals_out, sizeof(uint32_t) * (size_t)p.W * n) != hipSuccess || hipMalloc(&b->d_dense, sizeof(uint32_t) * ((size_t)p.n_buckets + 2)) != hipSuccess ||
-        hipMalloc(&b->d_sort_tmp, b->sort_tmp_bytes) != hipSuccess || hipMalloc(&b->d_part_ws, sizeof(uint32_t) * msm_sort_partition_ws_words()) != hipSuccess) {
+  if (sort_mode((uint64_t)p.W * n) == SORT_PART) {
+    // (key, value) buffers of the two-level counting sort: failing to get them only falls back to the histogram-atomic sort
+    if (hipMalloc(&b->d_keys_out, sizeof(uint32_t) * (size_t)p.W * n) != hipSuccess || hipMalloc(&b->d_vals_out, sizeof(uint32_t) * (size_t)p.W * n) != hipSuccess ||
+        hipMalloc(&b->d_part_ws, sizeof(uint32_t) * msm_sort_partition_ws_words()) != hipSuccess) {
       (void)hipGetLastError();
-      for (void* q : {(void*)b->d_keys_out, (void*)b->d_vals_out, (void*)b->d_dense, b->d_sort_tmp, (void*)b->d_part_ws}) if (q) (void)hipFree(q);
-      b->d_keys_out = b->d_vals_out = b->d_dense = nullptr; b->d_sort_tmp = nullptr; b->sort_tmp_bytes = 0; b->d_part_ws = nullptr;
+      for (void* q : {(void*)b->d_keys_out, (void*)b->d_vals_out, (void*)b->d_part_ws}) if (q) (void)hipFree(q);
+      b->d_keys_out = b->d_vals_out = nullptr; b->d_part_ws = nullptr;
     }
   }
   HIP_TRY(hipMalloc(&b->d_buckets, sizeof(uint32_t) * PW * (size_t)p.n_buckets));
@@ -239,7 +224,7 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
     // thirteen steps instead of seventeen --; from 8192 points on 18 is still best: profiles/r04/flow_window_sweep.txt)
     if (C::F::DEG == 1) pc = pick_precomp_bits(n, 8.0, n <= 4096 ? 14 : 18);
     else if (C::F::DEG == 2) pc = pick_precomp_bits(n, 8.0, n >= ((size_t)1 << 16) ? 18 : 2);
-    else pc = (n <= ((size_t)1 << 15) && !getenv("MNT753_MSM_PRE_C")) ? 14 : pick_precomp_bits(n, 8.0, 2);
+    else pc = n <= ((size_t)1 << 15) ? 14 : pick_precomp_bits(n, 8.0, 2);
     pW = (754 + pc - 1) / pc;
     if ((uint64_t)pW * n >= 0x7fffffffull) { want_table = false; pc = 0; pW = 1; }   // row index must fit 31 bits
   }
@@ -273,14 +258,9 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
     using CS = typename SplitOf<C>::type;
     for (size_t i0 = 0; i0 < n; i0 += tile) {
       const size_t cnt = std::min(tile, n - i0);
-      bool split = false;
-      if constexpr (!std::is_void<CS>::value) {
-        if (use_split_acc<C>()) {
-          split = true;
-          hipLaunchKernelGGL((k_precompute_windows<CS>), dim3(blocks_for<typename CS::F>(cnt)), dim3(256), 0, 0, b->d_aff, b->d_inf, ztmp, ptmp, n, i0, cnt, pc, pW);
-        }
-      }
-      if (!split)
+      if constexpr (!std::is_void<CS>::value)
+        hipLaunchKernelGGL((k_precompute_windows<CS>), dim3(blocks_for<typename CS::F>(cnt)), dim3(256), 0, 0, b->d_aff, b->d_inf, ztmp, ptmp, n, i0, cnt, pc, pW);
+      else
         hipLaunchKernelGGL((k_precompute_windows<C>), dim3(blocks_for<typename C::F>(cnt)), dim3(256), 0, 0, b->d_aff, b->d_inf, ztmp, ptmp, n, i0, cnt, pc, pW);
     }
     HIP_TRY(hipGetLastError());
@@ -334,13 +314,8 @@ void horner_host(const uint64_t* wire_pts, int n_sets, int c, uint64_t* out) {
 
 // Pairing levels (k_pair_level, MNT753_MSM_PAIR = number of levels) + accumulate over the shortened list.
 // Lanes per level: one round of the machine at one wave per SIMD, every lane in use down to batches of PAIR_MIN_B additions per
-// inversion.  MNT753_PAIR_LANES / MNT753_PAIR_MINB are development overrides.
-inline uint32_t pair_env(const char* name, uint32_t dflt) { const char* e = getenv(name); int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; }
-#ifndef MNT753_IRR_DEFAULT
-#define MNT753_IRR_DEFAULT 1
-#endif
-#define PAIR_MAX_LANES pair_env("MNT753_PAIR_LANES", 65536u)
-#define PAIR_MIN_B pair_env("MNT753_PAIR_MINB", 8u)
+// inversion.
+constexpr uint32_t PAIR_MAX_LANES = 65536u, PAIR_MIN_B = 8u;
 // Levels of the pairing pass for an MSM with `entries` sorted entries, from the one-GPU slice sweep of round 3
 // (tools/slice_sweep.py, profiles/r03/slice_sweep.json: every size an 8-way split of the benchmark configurations produces, levels
 // 0..4).  What a level costs besides its products is one inversion per lane (0.3 ms of wave time whatever the batch length), so
@@ -349,7 +324,7 @@ inline uint32_t pair_env(const char* name, uint32_t dflt) { const char* e = gete
 // 9.4 ms with the floor, against 10.2 ms without levels.  MNT753_MSM_PAIR=<levels> overrides, 0 turns the pass off.
 template <class V>
 int pair_levels(uint64_t entries) {
-  if constexpr (V::F::DEG != 1 && V::F::LANES == 1) return 0;   // one-lane Fq2 / Fq3: the state does not fit, no pairing
+  if constexpr (V::F::DEG != 1 && V::F::LANES == 1) return 0;   // (one-lane Fq2 / Fq3: not instantiated by the product)
   else {
     if (const char* e = getenv("MNT753_MSM_PAIR")) { int v = atoi(e); return v < 0 ? 0 : (v > 6 ? 6 : v); }
     if constexpr (V::F::LANES == 1) {          // G1: 2^18 points and up (2^17: 5.3 ms plain, 5.5 with two levels)
@@ -374,7 +349,6 @@ int pair_levels(uint64_t entries) {
 template <class C>
 int irr_levels_for(uint64_t entries, int regular_levels, uint32_t n_buckets) {
   if (const char* e = getenv("MNT753_MSM_IRR")) { int v = atoi(e); return v < 0 ? 0 : (v > 8 ? 8 : v); }
-  if (!MNT753_IRR_DEFAULT) return 0;
   const double lanes = (double)std::min<uint32_t>(machine_lanes(C::F::LANES), C::F::LANES == 3 ? PAIR_MAX_LANES / 3u : PAIR_MAX_LANES / (uint32_t)C::F::LANES);
   const double min_batch = C::F::LANES == 1 ? 16.0 : 10.0;
   double slots = (double)entries / (double)(1u << regular_levels) + 0.5 * n_buckets;
@@ -435,20 +409,20 @@ int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p, size_t n) {
 template <class C>
 int ensure_pair_ws_for(mnt753_bases* b, const MsmPlan& p, size_t n) {
   using CS = typename SplitOf<C>::type;
-  if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return ensure_pair_ws<CS, C>(b, p, n); }
-  return ensure_pair_ws<C, C>(b, p, n);
+  if constexpr (!std::is_void<CS>::value) return ensure_pair_ws<CS, C>(b, p, n);
+  else return ensure_pair_ws<C, C>(b, p, n);
 }
 template <class C>
 int pair_levels_for(uint64_t entries) {
   using CS = typename SplitOf<C>::type;
-  if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return pair_levels<CS>(entries); }
-  return pair_levels<C>(entries);
+  if constexpr (!std::is_void<CS>::value) return pair_levels<CS>(entries);
+  else return pair_levels<C>(entries);
 }
 template <class C>
 int irr_levels_for_group(uint64_t entries, int regular_levels, uint32_t n_buckets) {
   using CS = typename SplitOf<C>::type;
-  if constexpr (!std::is_void<CS>::value) { if (use_split_acc<C>()) return irr_levels_for<CS>(entries, regular_levels, n_buckets); }
-  return irr_levels_for<C>(entries, regular_levels, n_buckets);
+  if constexpr (!std::is_void<CS>::value) return irr_levels_for<CS>(entries, regular_levels, n_buckets);
+  else return irr_levels_for<C>(entries, regular_levels, n_buckets);
 }
 // plan of an MSM over n points of base set b: make_plan + the pairing levels this group / base set runs with
 template <class C>
@@ -568,18 +542,8 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
     // accumulate over at most `cap` entries: one round of the machine
     const uint32_t lanes_acc = std::min<uint32_t>(p.n_lanes, machine_lanes(V::F::LANES));
     const uint32_t T2 = (uint32_t)std::max<uint64_t>((cap + lanes_acc - 1) / lanes_acc, 8);
-    {
-      // the blocked accumulate prefetches its rows through 112 KB of dynamic LDS per workgroup: opt in once per kernel and device
-      static std::atomic<uint32_t> acc_lds_set{0};
-      const uint32_t dev_bit = 1u << (b->device & 31);
-      const size_t acc_lds = MNT753_ACC_PREFETCH ? ACC_LDS_BYTES : 0;
-      if (acc_lds && !(acc_lds_set.load(std::memory_order_acquire) & dev_bit)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_accumulate<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES));
-        acc_lds_set.fetch_or(dev_bit, std::memory_order_release);
-      }
-      hipLaunchKernelGGL((k_bucket_accumulate<V, true>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), acc_lds, st, src, b->d_sorted2,
-                         offs_acc, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
-    }
+    hipLaunchKernelGGL((k_bucket_accumulate<V, true>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, src, b->d_sorted2,
+                       offs_acc, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
     *acc_lanes = lanes_acc;
     *acc_T = T2;
     *acc_offs = offs_acc;
@@ -590,19 +554,10 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
   }
 }
 
-// one addition per group of lanes in the launches that are one addition deep (msm_flow.hip.h): on unless MNT753_FLOW=0
-inline bool flow_enabled() {   // (read per call, like the other switches of the merge: the tests flip them inside one process)
-  const char* e = getenv("MNT753_FLOW");
-  return !(e && atoi(e) == 0);
-}
-
 // The stages that run point arithmetic.  V = the configuration the point-operation VM is instantiated with (C itself,
 // or its lane-split counterpart); kernels that only move points are layout-agnostic and use C.
 template <class V, class C>
 int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_aff, mnt753_bases* b, uint32_t** result) {
-  // development: MNT753_SPLIT_MASK selects which kernels run lane-split (bit 0 accumulate, 1 edge sum, 2 bucket reduce, 3 tree)
-  unsigned mask = 0xf;
-  if (const char* e = getenv("MNT753_SPLIT_MASK")) mask = (unsigned)atoi(e);
   const int n_pair_levels = p.pair_levels;
   uint32_t acc_lanes = p.n_lanes;   // lanes the accumulate kernel ran with (= edge slots / 2)
   uint32_t acc_T = p.T;             // entries per lane it was given, and the bucket offsets it walked (the last level's, behind pairing levels)
@@ -612,20 +567,14 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
   if (n_pair_levels > 0) {
     if (int rc = pair_and_accumulate<V, C>(p, n, st, d_aff, b, &acc_lanes, &acc_T, &acc_offs)) return rc;
   } else {
-    if (mask & 1u)
-      hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
-                         p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
-    else
-      hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3(blocks_for<typename C::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
-                         p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
+    hipLaunchKernelGGL((k_bucket_accumulate<V>), dim3(blocks_for<typename V::F>(p.n_lanes)), dim3(256), 0, st, d_aff, b->d_sorted, b->d_offsets,
+                       p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, p.T, p.n_lanes);
   }
   HIP_TRY(hipEventRecord(b->ev[2], st));
-  // the edge pieces of the buckets that span several lanes: a K-ary tree over the lanes of every bucket (k_edge_tree_level; round 4),
-  // or the pointer-jumping merge of rounds 1-3 (MNT753_EDGE_TREE=0)
-  const bool edge_tree = !(getenv("MNT753_EDGE_TREE") && atoi(getenv("MNT753_EDGE_TREE")) == 0);
-  if (edge_tree) {
+  // the edge pieces of the buckets that span several lanes: a binary tree over the lanes of every bucket, in place (round 4)
+  {
     const uint32_t n_slots = 2 * acc_lanes;
-    const unsigned gs = (n_slots + 255) / 256, gv = blocks_for<typename V::F>(n_slots);
+    const unsigned gs = (n_slots + 255) / 256;
     const uint32_t blocked = n_pair_levels > 0 ? 1u : 0u;
     // (T, lanes) the accumulate kernel ran with: its BLOCKED form takes T2 and derives the real share from the list's actual length
     const uint32_t t_arg = n_pair_levels > 0 ? acc_T : p.T;
@@ -634,71 +583,29 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
     uint32_t level = 0;
     // A level is one addition deep, and its nodes are a LIST (msm_flow.hip.h): k_edge_nodes writes the first one, every level appends
     // the nodes of the next as its last act, launches are sized for the most nodes the level can have.  A level that can hold at most
-    // MNT753_EDGE_FLOW_NODES additions (default 32768 for the base fields, 16384 for Fq2 / Fq3; estimated as lanes / 2^l: one node
-    // per lane boundary at the first level, half as many per level after it) spreads each addition over a group of lanes, the levels
-    // before it run one VM addition per lane over the list.  MNT753_FLOW=0: the slot-driven levels of the first tree (no lists).
-    const uint64_t flow_edge_nodes = getenv("MNT753_EDGE_FLOW_NODES") ? strtoull(getenv("MNT753_EDGE_FLOW_NODES"), nullptr, 10)
+    // EDGE_FLOW_NODES additions (estimated as lanes / 2^l: one node per lane boundary at the first level, half as many per level after
+    // it) spreads each addition over a group of lanes, the levels before it run one VM addition per lane over the list.
+    // MNT753_EDGE_FLOW_NODES moves the boundary: the tests use it to run EVERY level of deep trees through either form (the inlined VM
+    // addition of round 4's first tree kernel was miscompiled exactly there).
+    const uint64_t EDGE_FLOW_NODES = getenv("MNT753_EDGE_FLOW_NODES") ? strtoull(getenv("MNT753_EDGE_FLOW_NODES"), nullptr, 10)
                                      : (C::F::DEG == 1 ? 32768 : (Flow<C>::K3 ? 8192 : 16384));   // (K3: two additions per wave, 2048 per round)
     uint32_t* counts = b->d_edge_flags + 40;               // nodes of level l, behind the 40 flags
-    uint4* lists[2] = {reinterpret_cast<uint4*>(b->d_edge_tmp), reinterpret_cast<uint4*>(b->d_edge_tmp) + acc_lanes};   // the old merge's temporary: 2 x lanes entries fit many times
+    uint4* lists[2] = {reinterpret_cast<uint4*>(b->d_edge_tmp), reinterpret_cast<uint4*>(b->d_edge_tmp) + acc_lanes};
     uint32_t parity = 0;
-    if (flow_enabled() && acc_lanes > 1)
+    if (acc_lanes > 1)
       hipLaunchKernelGGL((k_edge_nodes<C>), dim3(gs), dim3(256), 0, st, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked, 1u, b->d_edge_flags, 0u, lists[0], counts);
     for (uint64_t stride = 1; stride < acc_lanes; stride *= EDGE_TREE_K, ++level) {
-      if (flow_enabled()) {
-        // most nodes the level can have: two pieces per lane, a node takes two pieces `stride` apart
-        const uint64_t most = std::min<uint64_t>(acc_lanes, 2 * ((uint64_t)acc_lanes / stride) + 1);
-        if (acc_lanes / stride <= flow_edge_nodes)
-          hipLaunchKernelGGL((k_edge_tree_level_list<C>), dim3((unsigned)((most + Flow<C>::PER_WAVE - 1) / Flow<C>::PER_WAVE)), dim3(64), 0, st, b->d_edges, offs, p.n_buckets,
-                             t_arg, acc_lanes, blocked, (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
-        else if (mask & 2u)
-          hipLaunchKernelGGL((k_edge_tree_level_vmlist<V>), dim3(blocks_for<typename V::F>(most)), dim3(256), 0, st, b->d_edges, offs, p.n_buckets, t_arg, acc_lanes, blocked,
-                             (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
-        else
-          hipLaunchKernelGGL((k_edge_tree_level_vmlist<C>), dim3(blocks_for<typename C::F>(most)), dim3(256), 0, st, b->d_edges, offs, p.n_buckets, t_arg, acc_lanes, blocked,
-                             (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
-        parity ^= 1u;
-        continue;
-      }
-      if (mask & 2u)
-        hipLaunchKernelGGL((k_edge_tree_level<V>), dim3(gv), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked,
-                           (uint32_t)stride, b->d_edge_flags, level);
+      // most nodes the level can have: two pieces per lane, a node takes two pieces `stride` apart
+      const uint64_t most = std::min<uint64_t>(acc_lanes, 2 * ((uint64_t)acc_lanes / stride) + 1);
+      if (acc_lanes / stride <= EDGE_FLOW_NODES)
+        hipLaunchKernelGGL((k_edge_tree_level_list<C>), dim3((unsigned)((most + Flow<C>::PER_WAVE - 1) / Flow<C>::PER_WAVE)), dim3(64), 0, st, b->d_edges, offs, p.n_buckets,
+                           t_arg, acc_lanes, blocked, (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
       else
-        hipLaunchKernelGGL((k_edge_tree_level<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked,
-                           (uint32_t)stride, b->d_edge_flags, level);
+        hipLaunchKernelGGL((k_edge_tree_level_vmlist<V>), dim3(blocks_for<typename V::F>(most)), dim3(256), 0, st, b->d_edges, offs, p.n_buckets, t_arg, acc_lanes, blocked,
+                           (uint32_t)stride, lists[parity], counts + level, lists[parity ^ 1u], counts + level + 1);
+      parity ^= 1u;
     }
     hipLaunchKernelGGL((k_edge_tree_finish<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, offs, p.n_buckets, t_arg, acc_lanes, blocked, b->d_buckets);
-    if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
-      if (n_pair_levels > 0)
-        hipLaunchKernelGGL((k_pair_fix<V>), dim3(blocks_for<typename V::F>(p.n_buckets)), dim3(256), 0, st, b->d_buckets, b->d_fix, b->d_gen, p.n_buckets);
-    }
-  } else {
-    const uint32_t n_slots = 2 * acc_lanes;
-    const unsigned gs = (n_slots + 255) / 256, gv = blocks_for<typename V::F>(n_slots);
-    HIP_TRY(hipMemsetAsync(b->d_edge_flags, 0, sizeof(uint32_t) * 40, st));
-    uint32_t level = 0;
-    static const bool edge_pair = !(getenv("MNT753_EDGE_PAIR") && atoi(getenv("MNT753_EDGE_PAIR")) == 0);
-    for (uint32_t dist = 1; dist < n_slots; dist <<= 1, ++level) {
-      if constexpr (V::F::LANES == 3) {
-        // three-lane Fq3: a level is one projective addition deep (110 us through the VM); two triples per addition
-        if (edge_pair && (mask & 2u)) {
-          hipLaunchKernelGGL((k_edge_level_sum_pair<V>), dim3((n_slots + 39) / 40), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
-                             b->d_edge_flags, level);
-          hipLaunchKernelGGL((k_edge_level_copy<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
-                             b->d_edge_flags, level);
-          continue;
-        }
-      }
-      if (mask & 2u)
-        hipLaunchKernelGGL((k_edge_level_sum<V>), dim3(gv), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
-                           b->d_edge_flags, level);
-      else
-        hipLaunchKernelGGL((k_edge_level_sum<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
-                           b->d_edge_flags, level);
-      hipLaunchKernelGGL((k_edge_level_copy<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_edge_tmp, n_slots, dist,
-                         b->d_edge_flags, level);
-    }
-    hipLaunchKernelGGL((k_edge_finish<C>), dim3(gs), dim3(256), 0, st, b->d_edges, b->d_edge_bucket, b->d_buckets, n_slots);
     if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
       if (n_pair_levels > 0)
         hipLaunchKernelGGL((k_pair_fix<V>), dim3(blocks_for<typename V::F>(p.n_buckets)), dim3(256), 0, st, b->d_buckets, b->d_fix, b->d_gen, p.n_buckets);
@@ -708,49 +615,35 @@ int point_stages(const MsmPlan& p, size_t n, hipStream_t st, const uint32_t* d_a
   {
     const uint32_t k = (uint32_t)p.c - 1u, NS = p.n_sets;
     // the narrowest steps: one group of lanes per addition (four products deep instead of fourteen / eight), up to the number of
-    // additions at which the kernels below, with more additions per wave, catch up (MNT753_REDUCE_FLOW_MAX moves it)
-    const uint64_t flow_max = !flow_enabled() ? 0 : getenv("MNT753_REDUCE_FLOW_MAX") ? strtoull(getenv("MNT753_REDUCE_FLOW_MAX"), nullptr, 10)
-                              : (C::F::DEG == 3 ? (Flow<C>::K3 ? 8192 : 16384) : (C::F::DEG == 2 ? 4096 : 8192));
+    // additions at which the kernels below, with more additions per wave, catch up
+    constexpr uint64_t FLOW_MAX = C::F::DEG == 3 ? (Flow<C>::K3 ? 8192 : 16384) : (C::F::DEG == 2 ? 4096 : 8192);
+    constexpr uint64_t PAIR_MAX = 65536;   // lanes: up to here the two-lanes-per-addition step of the base fields and the two-lane Fq2
     for (uint32_t step = 0; step < k; ++step) {
       const uint64_t items = (uint64_t)NS * red_items(k, step);
-      if (items <= flow_max) {
+      if (items <= FLOW_MAX) {
         hipLaunchKernelGGL((k_reduce_step_flow<C>), dim3((unsigned)((items + Flow<C>::PER_WAVE - 1) / Flow<C>::PER_WAVE)), dim3(64), 0, st, b->d_buckets, b->d_offsets,
                            b->d_part_a, b->d_part_b, NS, k, step);
         continue;
       }
-      // narrow steps of a base field: two lanes per addition (8 sequential products instead of 14), MNT753_REDUCE_PAIR=0 turns it off
-      static const bool pair_tail = !(getenv("MNT753_REDUCE_PAIR") && atoi(getenv("MNT753_REDUCE_PAIR")) == 0);
-      static const uint64_t pair_max = getenv("MNT753_REDUCE_PAIR_MAX") ? strtoull(getenv("MNT753_REDUCE_PAIR_MAX"), nullptr, 10) : 65536;   // lanes
       if constexpr (C::F::LANES == 1 && C::F::DEG == 1) {
-        static const bool line = !(getenv("MNT753_REDUCE_LINE") && atoi(getenv("MNT753_REDUCE_LINE")) == 0);   // wide steps: straight-line addition instead of the VM's
-        if (line && 2 * items > pair_max) {
+        // wide steps: straight-line additions instead of the VM's; middle steps: two lanes per addition (8 sequential products instead of 14)
+        if (2 * items > PAIR_MAX)
           hipLaunchKernelGGL((k_reduce_step_line<C>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
-          continue;
-        }
-        if (pair_tail && 2 * items <= pair_max) {
+        else
           hipLaunchKernelGGL((k_reduce_step_pair<C>), dim3((unsigned)((2 * items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
-          continue;
+      } else {
+        // lane-split fields: the VM in the wide steps; the two-lane Fq2 with four lanes per addition in the middle ones (three-lane
+        // Fq3: six lanes per addition were measured 2.4x slower than the VM here in round 3 and are not used)
+        bool done = false;
+        if constexpr (V::F::LANES == 2) {
+          if (4 * items <= PAIR_MAX) {
+            hipLaunchKernelGGL((k_reduce_step_pair<V>), dim3((unsigned)((4 * items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
+            done = true;
+          }
         }
-      } else if constexpr (V::F::LANES == 2) {
-        if (pair_tail && (mask & 4u) && 4 * items <= pair_max) {
-          hipLaunchKernelGGL((k_reduce_step_pair<V>), dim3((unsigned)((4 * items + 255) / 256)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
-          continue;
-        }
-      } else if constexpr (V::F::LANES == 3) {
-        // three-lane Fq3: six lanes per addition, ten additions per wave.  Measured and NOT used (round 3, MNT6753 G2 2^15: reduction
-        // 4.2 ms through the VM, 10.0 ms with this kernel -- ten instead of twenty-one additions per wave and ~270 ds_bpermute per
-        // addition on top of the multiplier's own exchanges); MNT753_REDUCE_PAIR3=1 turns it on.  The edge merge, one addition per
-        // level whatever the width, does gain from the same addition core (k_edge_level_sum_pair: 4.65 -> 4.21 ms).
-        static const bool pair3 = getenv("MNT753_REDUCE_PAIR3") && atoi(getenv("MNT753_REDUCE_PAIR3")) != 0;
-        if (pair3 && pair_tail && (mask & 4u) && 6 * items <= 4 * pair_max) {
-          hipLaunchKernelGGL((k_reduce_step_pair<V>), dim3((unsigned)((items + 39) / 40)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
-          continue;
-        }
+        if (!done)
+          hipLaunchKernelGGL((k_reduce_step<V>), dim3(blocks_for<typename V::F>(items)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
       }
-      if (mask & 4u)
-        hipLaunchKernelGGL((k_reduce_step<V>), dim3(blocks_for<typename V::F>(items)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
-      else
-        hipLaunchKernelGGL((k_reduce_step<C>), dim3(blocks_for<typename C::F>(items)), dim3(256), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, NS, k, step);
     }
     hipLaunchKernelGGL((k_reduce_collect<C>), dim3((NS * (k + 1u) + 63) / 64), dim3(64), 0, st, b->d_buckets, b->d_offsets, b->d_part_a, b->d_part_b, b->d_tmp, NS, k);
   }
@@ -793,11 +686,6 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
     if (int rc = msm_sort_partition(C::FR, d_scal, d_inf, n, p, p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u, b->d_keys_out, b->d_vals_out,
                                     b->d_part_ws, b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, st))
       return rc;
-  } else if (b->d_sort_tmp && use_radix_sort((uint64_t)p.W * n)) {
-    if (int rc = msm_sort_radix(C::FR, d_scal, d_inf, n, p, p.pre ? (uint32_t)b->n : 0u, p.pre ? (uint32_t)base_offset : 0u,
-                                reinterpret_cast<uint32_t*>(b->d_digits), b->d_rank, b->d_keys_out, b->d_vals_out, b->d_sort_tmp, b->sort_tmp_bytes, b->d_dense,
-                                b->d_hist, b->d_offsets, b->d_cursor, b->d_blocksums, b->d_total, b->d_sorted, st))
-      return rc;
   } else {
     HIP_TRY(hipMemsetAsync(b->d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
     const unsigned gb = (unsigned)((n + 255) / 256);
@@ -819,12 +707,12 @@ int msm_start_t(mnt753_bases* b, size_t base_offset, const uint64_t* scalars, in
   // mnt753_msm_order_after: the sort above ran whenever it could; the kernels that fill the chip start once the other set's have ended
   if (b->after_ev) { HIP_TRY(hipStreamWaitEvent(st, b->after_ev, 0)); b->after_ev = nullptr; b->after_owner = nullptr; }
   // point stages: with the lane-split configuration of the group (Fq2: two lanes per point, Fq3: three) when it has
-  // one, otherwise one lane per point.  MNT753_MSM_ACC=vm forces one lane.
+  // one, otherwise one lane per point
   uint32_t* cur = nullptr;
   {
     int rc;
     using CS = typename SplitOf<C>::type;
-    if constexpr (!std::is_void<CS>::value) rc = use_split_acc<C>() ? point_stages<CS, C>(p, n, st, d_aff, b, &cur) : point_stages<C, C>(p, n, st, d_aff, b, &cur);
+    if constexpr (!std::is_void<CS>::value) rc = point_stages<CS, C>(p, n, st, d_aff, b, &cur);
     else rc = point_stages<C, C>(p, n, st, d_aff, b, &cur);
     if (rc) return rc;
   }

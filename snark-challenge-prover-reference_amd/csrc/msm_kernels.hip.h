@@ -8,8 +8,8 @@
 //   k_bases_to_internal   wire affine bases -> device form (27x28-bit limbs, R'=2^756), once per base set
 //   k_precompute_windows  window table 2^(cw) P_i (affine), once per base set: every window then indexes ONE bucket set
 //   sort stage            Montgomery scalar -> integer (as_bigint), signed radix-2^c Booth digits, (bucket, entry) pairs; from 2^22
-//                         entries a device radix sort (msm_sort.hip), below that k_scalar_digits / scan / k_scatter (histogram
-//                         with atomics + counting sort); buckets padded to a multiple of 2^levels entries either way
+//                         entries the two-level counting sort of msm_sort.hip, below that k_scalar_digits / scan / k_scatter
+//                         (histogram with atomics + counting sort); buckets padded to a multiple of 2^levels entries either way
 //   k_pair_level (x 3)    batched-affine additions of adjacent entries inside every bucket on a regular slot tree, operands staged
 //                         through LDS by row-cooperative LDS-DMA, one divstep inversion per lane batch (large sets only);
 //                         k_pair_fix undoes the stand-in of cancelled pairs
@@ -18,7 +18,7 @@
 //                         each lane goes to an edge array.  Straight-line mixed additions for base fields and the two-lane
 //                         Fq2, the point VM (curve753.hip.h) otherwise
 //   k_edge_tree_*         the edge pieces that belong to one bucket, summed by an in-place binary tree over the bucket's lane range
-//                         (round 4; k_edge_level_*: the pointer-jumping merge of rounds 1-3, MNT753_EDGE_TREE=0)
+//                         (round 4; the pointer-jumping merge of rounds 1-3 left the product in round 5)
 //   k_reduce_step*        bucket reduction by halving: c - 1 launches, each one group addition deep (T and the G_l of
 //                         sum_b (b+1) B[b] = T + sum_l 2^l G_l): _line = straight-line additions (wide steps, base fields),
 //                         _pair = two lanes per addition (middle steps), plain = the VM; k_reduce_collect gathers the c
@@ -38,14 +38,10 @@ namespace mnt753 {
 constexpr int FPS_WORDS = 28;            // storage words per base-field element (27 limbs + pad), 112 B
 constexpr uint32_t EDGE_NONE = 0xffffffffu;
 
-// waves per SIMD requested for the point-arithmetic kernels: the base-field and lane-split instantiations keep their state in
-// the 512-register file at one wave per SIMD; the one-lane Fq2 / Fq3 kernels (MNT753_MSM_ACC=vm) spill whatever the budget and
-// two waves per SIMD (256 registers) were measured 3x slower (MNT753_G2_WAVES to override at build time)
-#ifndef MNT753_G2_WAVES
-#define MNT753_G2_WAVES 1
-#endif
+// one wave per SIMD for every point-arithmetic kernel: they keep their state in the 512-register file (two waves per SIMD at 256
+// registers were measured 3x slower for the extension fields, round 1)
 template <class C>
-constexpr int vm_waves() { return C::F::DEG == 1 ? 1 : MNT753_G2_WAVES; }
+constexpr int vm_waves() { return 1; }
 
 // ---- storage helpers ---------------------------------------------------------------------
 template <int M>
@@ -414,29 +410,8 @@ static __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restric
 //                  stride `plane_stride` uint4s, see k_pair_level): consecutive entries of a lane then sit in adjacent 16-byte
 //                  pieces of the same sectors, and the level's stores are contiguous KiB instead of 64 partial sectors each.
 __host__ __device__ __forceinline__ size_t blk_index(uint32_t j);
-__device__ __forceinline__ void glds16(const void* gsrc, const uint4* lds_dst_wave_uniform);
-__device__ __forceinline__ void wait_vm0();
-__device__ __forceinline__ void wait_lgkm0();
-template <int M>
-__device__ __forceinline__ uint32_t fp_from_lds(Fp<M>& r, const uint4* p, uint32_t stride);
-// BLOCKED instantiation, build option -DMNT753_ACC_PREFETCH=1: the rows of a lane's next entry are fetched by LDS-DMA while the
-// current mixed addition runs (two images of 14 quads x 64 lanes per wave, 112 KB per workgroup).  A lane walks its OWN run of
-// slots, so a wave's 64 loads of one piece go to 64 different lines and most of them miss the L1 (SQ counters of round 3: 27 % of
-// the wave cycles waited for them, VALU busy 61 %); one entry ahead that latency hides behind eleven products, with no register
-// spent on it.  Measured neutral (same-box A/B, profiles/r03/ab_acc_prefetch.txt: 22.65 / 22.99 ms without, 22.90 / 22.66 with):
-// the kernel's clock follows its utilisation (2.22 GHz at 61 % VALU-busy, 2.0 GHz at 85 %: the chip is power-limited under this
-// load), so waiting less buys a lower clock, not a shorter kernel.  Off by default: it would only hold 112 KB of LDS.
-constexpr uint32_t ACC_IMG_QUADS = 14u * 64u;
-constexpr uint32_t ACC_LDS_BYTES = 4u * 2u * ACC_IMG_QUADS * 16u;
-#ifndef MNT753_ACC_PREFETCH
-#define MNT753_ACC_PREFETCH 0
-#endif
-#ifndef MNT753_ACC_LINE_SPLIT
-#define MNT753_ACC_LINE_SPLIT 2   // lane-split fields of up to this many lanes per point also take the straight-line addition (measured: two-lane Fq2 -1.0 ms of 72, three-lane Fq3 neutral)
-#endif
-#ifndef MNT753_ACC_LINE
-#define MNT753_ACC_LINE 1     // base fields: straight-line mixed addition in k_bucket_accumulate instead of the VM's
-#endif
+// (An LDS-DMA prefetch of the next entry's row was built in round 3 and measured neutral -- the kernel's clock follows its
+// utilisation, profiles/r03/ab_acc_prefetch.txt -- and left the source in round 5.)
 // acc += Q (Q affine) in a straight line: the same eleven products as the VM's program 0..10 (mixed_add, mnt4753_g1.cpp:265-313),
 // without its switch machine.  pc == PC_MADD: add; anything else (PC_END): the lane keeps its value (it only took over Q) but runs the
 // same instructions.  Equal points fall back to the VM's doubling.  Base fields and the two-lane Fq2 (k_bucket_accumulate).
@@ -504,23 +479,7 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
   Proj<C> acc, Q;
   pt_set_zero(acc);
   F::one(Q.Z);
-  constexpr bool PREFETCH = BLOCKED && MNT753_ACC_PREFETCH;
-  // PREFETCH: entry e of the blocked list is row e of the planes (k_pair_level, last level: out_sorted[o] = (o << 1) | sign), so the
-  // address of the next row needs no load; only its sign does, and that is read one iteration ahead as well
-  extern __shared__ uint4 acc_lds[];
-  uint4* acc_img = acc_lds + (size_t)(threadIdx.x >> 6) * (2u * ACC_IMG_QUADS);
-  const uint32_t acc_lane = threadIdx.x & 63u;
-  auto issue_row = [=](uint32_t row, uint32_t buf) __attribute__((always_inline)) {
-    const uint4* px = reinterpret_cast<const uint4*>(bases) + (size_t)(row & 1u) * plane_stride + blk_index((row >> 1) * F::LANES + lane_comp<F>());
-#pragma unroll
-    for (uint32_t i = 0; i < 7; ++i) {
-      glds16(px + (size_t)i * 64, acc_img + buf * ACC_IMG_QUADS + i * 64u);
-      glds16(px + 2 * plane_stride + (size_t)i * 64, acc_img + buf * ACC_IMG_QUADS + (7u + i) * 64u);
-    }
-  };
-  uint32_t s_next = 0, it = 0;
-  if constexpr (PREFETCH) { s_next = sorted[e]; issue_row(e, 0u); }
-  for (; e < end; ++e, ++it) {
+  for (; e < end; ++e) {
     if (e == next) {
       // bucket b is finished inside this segment
       if (first_run) {
@@ -534,15 +493,7 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
       do { ++b; next = offsets[b + 1]; } while (next == e);
     }
     uint32_t s;
-    if constexpr (PREFETCH) {
-      s = s_next << 31;
-      wait_vm0();                                    // the image of this entry (issued one mixed addition ago)
-      const uint4* im = acc_img + (it & 1u) * ACC_IMG_QUADS + acc_lane;
-      (void)fp_from_lds(Q.X, im, 64u);
-      (void)fp_from_lds(Q.Y, im + 7u * 64u, 64u);
-      wait_lgkm0();
-      if (e + 1u < end) { s_next = sorted[e + 1u]; issue_row(e + 1u, (it + 1u) & 1u); }
-    } else if constexpr (BLOCKED) {
+    if constexpr (BLOCKED) {
       s = sorted[e];
       static_assert(F::DEG == 1 || F::LANES > 1, "blocked rows hold one component per thread");
       // entries of the blocked list are (row << 1) | sign: with the sign in bit 31 hipcc 7.2 dropped the mask from
@@ -574,8 +525,8 @@ __global__ void __launch_bounds__(256, vm_waves<C>()) k_bucket_accumulate(const 
       acc.X = Q.X; acc.Y = Q.Y; F::one(acc.Z);
       pc = PC_END;
     }
-    if constexpr (((F::LANES == 1 && F::DEG == 1) || (F::LANES > 1 && F::LANES <= MNT753_ACC_LINE_SPLIT)) && MNT753_ACC_LINE) {
-      // base fields: the mixed addition in a straight line (the same eleven products as the VM's program 0..10, without its
+    if constexpr ((F::LANES == 1 && F::DEG == 1) || F::LANES == 2) {
+      // base fields and the two-lane Fq2 (-1.0 ms of 72; the three-lane Fq3 measured neutral): the mixed addition in a straight line (the same eleven products as the VM's program 0..10, without its
       // switch machine); lanes that only took over Q keep their value, equal points fall back to the VM's doubling
       MNT753_MADD_LINE(C, F, acc, Q, pc);
     } else {
@@ -698,30 +649,21 @@ __device__ __forceinline__ void fp_store_blk(uint4* __restrict__ base, uint32_t 
 //     rows   first level: [point 0 | 1][slot of the wave][quads of the row (x | y) or of x only]   (packed, lane-linear fill)
 //            later levels: [plane x-even | x-odd | y-even | y-odd][quad][thread]                    (own data, already coalesced)
 //     pre    [quad][thread] (the slot's kind rides in its pad word)     entries [4 buffers][2 * slots of the wave]  (first level: fetched three slots ahead)
-// The forward sweep only needs x: its half-size images alternate between the two halves of `rows`.  MNT753_PAIR_FWD_AHEAD=2
-// fetches them two slots ahead (s_waitcnt vmcnt(14) leaves the younger image in flight); measured: the wait at the top of a
-// slot is ~130 cycles either way, one slot ahead is the default.
+// The forward sweep only needs x: its half-size images alternate between the two halves of `rows`.  (Fetching them two slots ahead,
+// s_waitcnt vmcnt(14) leaving the younger image in flight, was measured in round 2: the wait at the top of a slot is ~130 cycles
+// either way; the variant left the source in round 5.)
 constexpr uint32_t PAIR_IMG_QUADS = 1792;                       // 2 points x 64 lanes x 14 quads (every field: NS * RQ * 2 <= 1792)
 constexpr uint32_t PAIR_LDS_WAVE_QUADS = PAIR_IMG_QUADS + 448 + 128;  // rows, prefix product, entries (4 x 128 u32)
 constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
-#ifndef MNT753_PAIR_DMA_STEPS_FIRST
-#define MNT753_PAIR_DMA_STEPS_FIRST 4
+// EXPERIMENT (round 5, default off): first level of a base field, every LDS-DMA instruction fetches WHOLE rows -- 4 rows x 14 quads
+// (56 lanes) of a full-row image, 9 rows x 7 quads (63 lanes) of an x image -- instead of 64 consecutive quads of the packed image,
+// which cross rows (4.6 rows per instruction, every lane dividing by 14 to find its row).  The image layout is unchanged.
+#ifndef MNT753_EXP_WHOLE_ROWS
+#define MNT753_EXP_WHOLE_ROWS 0
 #endif
-#ifndef MNT753_PAIR_DMA_STEPS_LATER
-#define MNT753_PAIR_DMA_STEPS_LATER 3
-#endif
-#ifndef MNT753_PAIR_FWD_AHEAD
-#define MNT753_PAIR_FWD_AHEAD 1
-#endif
-#ifndef MNT753_PAIR_LAZY
-#define MNT753_PAIR_LAZY 1
-#endif
-#ifndef MNT753_PAIR_SPLIT_PRELOAD
-#define MNT753_PAIR_SPLIT_PRELOAD 0
-#endif
-#ifndef MNT753_PAIR_OFF_PER_STEP
-#define MNT753_PAIR_OFF_PER_STEP 1     // first level: table offsets of the next slot read per portion (7 registers) instead of per slot (28)
-#endif
+// portions the LDS-DMA of the next slot's image is issued in, one ahead of each of the first products of a slot: gathered rows of a
+// base field in four, of the lane-split fields in five, own planes in three (profiles/r03/ab_first_level_dma_portions.txt)
+constexpr uint32_t PAIR_DMA_STEPS_FIRST = 4, PAIR_DMA_STEPS_LATER = 3;
 
 #ifdef MNT753_PAIR_TIMING
 // development: cycle totals of k_pair_level per wave (s_memtime): [0] forward, [1] inversion, [2] backward, [3] waves, [4..] ad hoc
@@ -746,7 +688,6 @@ __device__ __forceinline__ void glds4(const void* gsrc, const uint32_t* lds_dst_
   __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr_t)lds_dst_wave_uniform, 4, 0, 0);
 }
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); }     // vmcnt(0)
-__device__ __forceinline__ void wait_vm14() { __builtin_amdgcn_s_waitcnt(0x0f7e); asm volatile("" ::: "memory"); }    // vmcnt(14)
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); asm volatile("" ::: "memory"); }   // lgkmcnt(0)
 template <int M>
 __device__ __forceinline__ uint32_t fp_from_lds(Fp<M>& r, const uint4* p, uint32_t stride) {   // 7 quads at p, p + stride, ...
@@ -864,11 +805,12 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   // first level of a base field: the table offsets of the next slot's pieces are read out of the entry image ahead of the
   // loads (per portion).  The lane-split fields keep a ds_read in front of every piece: their multiplier leaves no registers.
   constexpr bool PRELOAD = first && LN == 1;
-  // backward sweep only: the per-portion offsets (seven registers, AGPRs will do) for the lane-split fields as well
-  constexpr bool PRELOAD_BWD = first && (LN == 1 || MNT753_PAIR_SPLIT_PRELOAD);
+  // backward sweep: the table offsets of the next slot read per portion (seven registers).  (For the lane-split fields the same
+  // was measured WORSE in round 3 -- scratch appears, profiles/r03/ab_g2_split_preload.txt -- so they keep the per-piece read.)
+  constexpr bool PRELOAD_BWD = first && LN == 1;
   // base fields: differences limb-wise without carries, signed-product multiplier, two normalisations per addition instead of
-  // seven carry-propagating subtractions (fp753.hip.h, "lazy arithmetic"); MNT753_PAIR_LAZY=0 builds the eager formulas
-  constexpr bool LAZY = has_lazy<F>::value && MNT753_PAIR_LAZY;
+  // seven carry-propagating subtractions (fp753.hip.h, "lazy arithmetic")
+  constexpr bool LAZY = has_lazy<F>::value;
   extern __shared__ uint4 pair_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint4* img = pair_lds + (size_t)wave * PAIR_LDS_WAVE_QUADS;
@@ -917,6 +859,12 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   auto irr_word = [=](uint32_t it) __attribute__((always_inline)) {
     return irr_src[min(it * NLe + (lane_on ? t : t0w), S - 1u)];
   };
+  // whole-row pieces (experiment): rows per instruction, quads of the image per instruction, this lane's row and quad inside a piece
+  constexpr bool WR = first && LN == 1 && MNT753_EXP_WHOLE_ROWS;
+  constexpr uint32_t WR_ROWS = 64u / RQ, WR_ROWS_X = 64u / XQ;                 // 4 and 9 for a base field
+  constexpr uint32_t DQ = WR ? WR_ROWS * RQ : 64u, DQX = WR ? WR_ROWS_X * XQ : 64u;
+  const uint32_t wr_j = min(lane / RQ, WR_ROWS - 1u), wr_q = lane - (lane / RQ) * RQ, wr_jx = lane / XQ, wr_qx = lane - (lane / XQ) * XQ;
+  const bool wr_on = lane < DQ;
   auto issue_row_piece = [=](uint32_t it, uint32_t buf, uint32_t k, auto xonly_c, uint4* im, uint32_t sw = 0u) __attribute__((always_inline)) {
     constexpr bool xonly = decltype(xonly_c)::value;
     if constexpr (IRR) {
@@ -924,6 +872,14 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       irr_bases(sw, va, vb);
       const uint32_t pl = k / 7u, q = k - pl * 7u;        // image planes: x1 | x2 | y1 | y2
       glds16(src_planes + (size_t)(pl & 2u) * src_stride + (size_t)q * 64 + ((pl & 1u) ? vb : va), im + k * 64u);
+    } else if constexpr (WR) {
+      constexpr uint32_t rows = xonly ? WR_ROWS_X : WR_ROWS, dq = xonly ? DQX : DQ;
+      const uint32_t rs = rows * k + (xonly ? wr_jx : wr_j);
+      if (lane < dq && rs < 2u * NS) {
+        const uint32_t e = ent_img[buf * 128u + 2u * (rs & (NS - 1u)) + (rs >= NS ? 1u : 0u)];
+        const uint32_t r = e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu);
+        glds16(table + (size_t)r * RQ + (xonly ? wr_qx : wr_q), im + dq * k);
+      }
     } else if constexpr (first) {
       constexpr uint32_t rq = xonly ? XQ : RQ;
       constexpr uint32_t total = 2u * NS * rq;
@@ -940,8 +896,8 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       glds16(src_planes + blk_index(j) + (size_t)pl * src_stride + (size_t)q * 64, im + k * 64u);
     }
   };
-  constexpr uint32_t ROW_PIECES_X = first ? (2u * NS * XQ + 63u) / 64u : 14u;
-  constexpr uint32_t ROW_PIECES = first ? (2u * NS * RQ + 63u) / 64u : 28u;
+  constexpr uint32_t ROW_PIECES_X = first ? (WR ? (2u * NS + WR_ROWS_X - 1u) / WR_ROWS_X : (2u * NS * XQ + 63u) / 64u) : 14u;
+  constexpr uint32_t ROW_PIECES = first ? (WR ? (2u * NS + WR_ROWS - 1u) / WR_ROWS : (2u * NS * RQ + 63u) / 64u) : 28u;
   auto issue_rows = [=](uint32_t it, uint32_t buf, auto xonly_c, uint4* im, uint32_t sw = 0u) __attribute__((always_inline)) {
     constexpr uint32_t n = decltype(xonly_c)::value ? ROW_PIECES_X : ROW_PIECES;
 #pragma unroll
@@ -951,6 +907,13 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   // A ds_read + s_waitcnt lgkmcnt(0) in front of EVERY LDS-DMA instruction cost a quarter of the level (the LDS queue is
   // busy with the DMA's own writes); the offsets of the next slot now sit in registers before the first piece is issued.
   auto row_offset = [=](uint32_t buf, uint32_t k) __attribute__((always_inline)) {      // piece k of a full-row image
+    if constexpr (WR) {
+      // rows WR_ROWS k .. WR_ROWS k + 3 never straddle the two points of the image (NS is a multiple of WR_ROWS): the entry index is a
+      // constant of the piece plus a constant of the lane
+      const uint32_t r0 = WR_ROWS * k;
+      const uint32_t e = ent_img[buf * 128u + (2u * (r0 & (NS - 1u)) + (r0 >= NS ? 1u : 0u)) + 2u * wr_j];
+      return (e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu)) * RQ + wr_q;
+    }
     const uint32_t i = min(64u * k + lane, 2u * NS * RQ - 1u);
     const uint32_t rs = i / RQ, q = i - rs * RQ;
     const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
@@ -964,6 +927,12 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     constexpr uint32_t n = xonly ? ROW_PIECES_X : ROW_PIECES;
 #pragma unroll
     for (uint32_t k = 0; k < n; ++k) {
+      if constexpr (WR && xonly) {
+        const uint32_t rs = min(WR_ROWS_X * k + wr_jx, 2u * NS - 1u);
+        const uint32_t e = ent_img[buf * 128u + 2u * (rs & (NS - 1u)) + (rs >= NS ? 1u : 0u)];
+        off[k] = (e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu)) * RQ + wr_qx;
+        continue;
+      }
       const uint32_t i = min(64u * k + lane, total - 1u);
       const uint32_t rs = i / rq, q = i - rs * rq;
       const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
@@ -996,52 +965,49 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   PAIR_T(tc0);
   PAIR_TW_DECL(tw_a); PAIR_TW_DECL(tw_b); PAIR_TW_DECL(tw_c); PAIR_TW_DECL(tw_d);
   constexpr uint32_t XIMG = PAIR_IMG_QUADS / 2u;          // one x-only image (14 pieces of 64 quads)
-  static_assert(ROW_PIECES_X * 64u <= XIMG, "x image");
+  static_assert(WR || ROW_PIECES_X * 64u <= XIMG, "x image");
   // x image of slot `it` -> half (it & 1) of the row image; first level: offsets from the entries in ent_img[it & 3]
   auto issue_x = [=](uint32_t it, uint32_t sw = 0u) __attribute__((always_inline)) {
     uint4* im = img + (it & 1u) * XIMG;
     issue_rows(it, it & 3u, std::true_type{}, im, sw);
   };
-  constexpr uint32_t AH = MNT753_PAIR_FWD_AHEAD;          // slots between the issue of an x image and its use
-  static_assert(!IRR || AH == 1u, "irregular levels fetch one slot ahead");
+  constexpr uint32_t AH = 1u;                             // slots between the issue of an x image and its use
   // IRR: the source words of this slot and the next (the one after that is loaded while this slot's product runs)
   uint32_t sw_cur = 0u, sw_nxt = 0u;
   if constexpr (IRR) { sw_cur = irr_word(0); sw_nxt = irr_word(min(1u, n_it - 1u)); }
   if constexpr (first) {
     issue_entries(0, 0);
     issue_entries(min(1u, n_it - 1u), 1);
-    if constexpr (AH == 2u) issue_entries(min(2u, n_it - 1u), 2);
     wait_vm0();
   }
   issue_x(0, sw_cur);
-  if constexpr (AH == 2u) { if (n_it > 1u) issue_x(1); }
   for (uint32_t it = 0; it < n_it; ++it) {
     const uint32_t o = it * NLe + t;
     const bool on = lane_on && o < S;
     uint32_t f0, f1;
     uint32_t sw_nn = 0u;
-    // the image of this slot is complete; the 14 loads of the next slot's image (issued after everything else of the previous
-    // iteration) may stay in flight -- vmcnt counts in issue order
-    if (AH == 2u && it + 1u < n_it) wait_vm14(); else wait_vm0();
+    wait_vm0();                                            // the image of this slot is complete
     read_rows(it & 3u, std::true_type{}, img + (it & 1u) * XIMG, f0, f1, x1, y1, x2, y2);
     if constexpr (IRR) { if (sw_cur >> 31) f1 = PF_EMPTY; }   // odd leftover: the second operand is the first one again
     const bool ahead = it + AH < n_it;
     uint32_t off[ROW_PIECES];
     if constexpr (PRELOAD) { if (ahead) load_row_offsets((it + AH) & 3u, std::true_type{}, off); }
     wait_lgkm0();
-    // image of slot it + AH into the half it will be read from (entries first, the 14 row loads last: see the wait above).
-    // One slot ahead: at once, the half is free; two slots ahead: after this slot's stores, into the half just read.
+    // image of slot it + AH into the half it will be read from (entries first, the 14 row loads last): at once, the half is free
     auto issue_ahead = [=](const uint32_t (&off)[ROW_PIECES]) __attribute__((always_inline)) {
       uint4* im = img + ((it + AH) & 1u) * XIMG;
       if constexpr (first) issue_entries(min(it + AH + 1u, n_it - 1u), (it + AH + 1u) & 3u);
       if constexpr (PRELOAD) {
 #pragma unroll
-        for (uint32_t k = 0; k < ROW_PIECES_X; ++k) glds16(table + off[k], im + 64u * k);
+        for (uint32_t k = 0; k < ROW_PIECES_X; ++k) {
+          if constexpr (WR) { if (lane < DQX && WR_ROWS_X * k + wr_jx < 2u * NS) glds16(table + off[k], im + DQX * k); }
+          else glds16(table + off[k], im + 64u * k);
+        }
       } else {
         issue_rows(it + AH, (it + AH) & 3u, std::true_type{}, im, sw_nxt);
       }
     };
-    if constexpr (AH == 1u) { if (ahead) issue_ahead(off); }
+    if (ahead) issue_ahead(off);
     if constexpr (IRR) { if (it + 2u < n_it) sw_nn = irr_word(it + 2u); }   // in flight during this slot's product
     uint32_t kind;
     if (!on || (f0 & PF_EMPTY)) kind = PK_EMPTY;
@@ -1079,7 +1045,6 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     PAIR_TW(tw_b, if (on) fp_store_blk(prefix_ws, o * LN + comp, run, kind));
     PAIR_T(tfa0);
     asm volatile("" ::: "memory");
-    if constexpr (AH == 2u) { if (ahead) issue_ahead(off); }
 #ifdef MNT753_PAIR_TIMING
     tw_a += __builtin_readcyclecounter() - tfa0;
 #endif
@@ -1135,8 +1100,6 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     const uint32_t vb_next = more ? (uint32_t)blk_index(min((it - 1u) * NLe + (lane_on ? t : t0w), S - 1u) * LN + comp) : 0u;
     uint32_t va_irr = 0u, vb_irr = 0u;        // IRR: per-lane parts of the next slot's two input slots
     if constexpr (IRR) { if (more) irr_bases(sw_nxt, va_irr, vb_irr); }
-    uint32_t off[ROW_PIECES];
-    if constexpr (PRELOAD_BWD && !MNT753_PAIR_OFF_PER_STEP) { if (more) load_row_offsets((n + 1u) & 1u, std::false_type{}, off); }
     wait_lgkm0();
     if constexpr (first) { if (more) issue_entries(it >= 2u ? it - 2u : 0u, n & 1u); }
     const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
@@ -1182,20 +1145,20 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       // (first level, round 3: four portions for the base fields -- the last one then has two products to land in instead of one:
       // G1 2^20 25.04 / 24.93 -> 24.54 / 24.12 ms, three portions 24.45 / 24.35; the lane-split Fq2 wants five: 66.9 / 67.3 ms against
       // 68.5 / 68.5 with four; profiles/r03/ab_first_level_dma_portions.txt)
-      constexpr uint32_t DMA_STEPS = first ? (LN == 1 ? MNT753_PAIR_DMA_STEPS_FIRST : 5u) : MNT753_PAIR_DMA_STEPS_LATER;
+      constexpr uint32_t DMA_STEPS = first ? (LN == 1 ? PAIR_DMA_STEPS_FIRST : 5u) : PAIR_DMA_STEPS_LATER;
       constexpr uint32_t PER_STEP = (BWD_PIECES + DMA_STEPS - 1u) / DMA_STEPS;
 #pragma nounroll
       for (int step = 0; step < 5; ++step) {
         PAIR_T(tdm0);
         if (more && (uint32_t)step < DMA_STEPS) {
-          // portion `step` of the next slot's image.  The pieces are named by constants (so that `off` stays in registers and
-          // plane / quad offsets are scalar constants), and the per-lane part of every address passes through an opaque move:
+          // portion `step` of the next slot's image.  The pieces are named by constants (so that plane / quad offsets are scalar
+          // constants), and the per-lane part of every address passes through an opaque move:
           // the 64-bit addresses are formed here, one VALU instruction each, not hoisted out of the step loop (35 live
           // addresses would not fit the register file) and not recomputed from the slot number either.
-          auto portion = [=](auto step_c, const uint32_t (&off)[ROW_PIECES], uint32_t vb) __attribute__((always_inline)) {
+          auto portion = [=](auto step_c, uint32_t vb) __attribute__((always_inline)) {
             constexpr uint32_t base = decltype(step_c)::value * PER_STEP;
             uint32_t offp[PER_STEP];
-            if constexpr (PRELOAD_BWD && MNT753_PAIR_OFF_PER_STEP) {
+            if constexpr (PRELOAD_BWD) {
               // the table offsets of this portion out of the entry image, one wait for all of them
 #pragma unroll
               for (uint32_t u = 0; u < PER_STEP; ++u) offp[u] = base + u < ROW_PIECES ? row_offset((n + 1u) & 1u, base + u) : 0u;
@@ -1206,9 +1169,10 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
               const uint32_t idx = base + u;
               if (idx < ROW_PIECES) {
                 if constexpr (PRELOAD_BWD) {
-                  uint32_t o = MNT753_PAIR_OFF_PER_STEP ? offp[u] : off[idx < ROW_PIECES ? idx : 0u];
+                  uint32_t o = offp[u];
                   asm volatile("" : "+v"(o));
-                  glds16(table + o, img + 64u * idx);
+                  if constexpr (WR) { if (wr_on) glds16(table + o, img + DQ * idx); }
+                  else glds16(table + o, img + 64u * idx);
                 } else if constexpr (first) {
                   uint32_t k = idx;
                   asm volatile("" : "+s"(k));
@@ -1233,11 +1197,11 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
             }
           };
           switch (step) {
-            case 0: portion(std::integral_constant<uint32_t, 0>{}, off, vb_next); break;
-            case 1: portion(std::integral_constant<uint32_t, 1>{}, off, vb_next); break;
-            case 2: portion(std::integral_constant<uint32_t, 2>{}, off, vb_next); break;
-            case 3: portion(std::integral_constant<uint32_t, 3>{}, off, vb_next); break;
-            default: portion(std::integral_constant<uint32_t, 4>{}, off, vb_next); break;
+            case 0: portion(std::integral_constant<uint32_t, 0>{}, vb_next); break;
+            case 1: portion(std::integral_constant<uint32_t, 1>{}, vb_next); break;
+            case 2: portion(std::integral_constant<uint32_t, 2>{}, vb_next); break;
+            case 3: portion(std::integral_constant<uint32_t, 3>{}, vb_next); break;
+            default: portion(std::integral_constant<uint32_t, 4>{}, vb_next); break;
           }
         }
 #ifdef MNT753_PAIR_TIMING
@@ -1374,59 +1338,6 @@ __device__ __forceinline__ int add_pc(Proj<C>& P, const Proj<C>& Q) {
   return PC_ADD;
 }
 
-// ---- edge combine ----------------------------------------------------------------------------------
-// Edge slots are ordered by bucket id (EDGE_NONE only at the tail).  The pieces of one bucket form a run of
-// consecutive slots; runs are reduced to their first slot by pointer jumping: at level s every slot adds
-// the slot 2^s further on if it belongs to the same bucket.  Depth is log2(longest run) for ANY digit
-// distribution (the top window alone produces runs of ~N/(2T) pieces).  Each level is two tiny kernels
-// (sum into tmp, copy back) so that no slot is read while it is rewritten; a device flag lets the levels
-// after the last useful one exit at once.
-template <class C>
-__global__ void __launch_bounds__(256, vm_waves<C>()) k_edge_level_sum(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
-                                                          uint32_t* __restrict__ tmp, uint32_t n_slots, uint32_t dist,
-                                                          uint32_t* __restrict__ flags, uint32_t level) {
-  if (level > 0 && flags[level - 1] == 0) return;   // no run longer than dist/1: nothing left to do
-  const uint32_t j = logical_lane<typename C::F>();
-  if (j >= n_slots || j + dist >= n_slots) return;
-  const uint32_t b = edge_bucket[j];
-  if (b == EDGE_NONE || edge_bucket[j + dist] != b) return;
-  Proj<C> acc, Q;
-  proj_load<C>(acc, edges + (size_t)j * proj_words<C>());
-  proj_load<C>(Q, edges + (size_t)(j + dist) * proj_words<C>());
-  int pc = add_pc<C>(acc, Q);
-  pt_vm<C, true>(acc, Q, pc);
-  proj_store<C>(tmp + (size_t)j * proj_words<C>(), acc);
-  flags[level] = 1;
-}
-template <class C>
-__global__ void __launch_bounds__(256) k_edge_level_copy(uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
-                                                        const uint32_t* __restrict__ tmp, uint32_t n_slots, uint32_t dist,
-                                                        const uint32_t* __restrict__ flags, uint32_t level) {
-  if (flags[level] == 0) return;
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_slots || j + dist >= n_slots) return;
-  const uint32_t b = edge_bucket[j];
-  if (b == EDGE_NONE || edge_bucket[j + dist] != b) return;
-  const uint4* src = reinterpret_cast<const uint4*>(tmp + (size_t)j * proj_words<C>());
-  uint4* dst = reinterpret_cast<uint4*>(edges + (size_t)j * proj_words<C>());
-#pragma unroll
-  for (int k = 0; k < proj_words<C>() / 4; ++k) dst[k] = src[k];
-}
-// the first slot of every run now holds the bucket's sum
-template <class C>
-__global__ void __launch_bounds__(256) k_edge_finish(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
-                                                    uint32_t* __restrict__ buckets, uint32_t n_slots) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_slots) return;
-  const uint32_t b = edge_bucket[j];
-  if (b == EDGE_NONE) return;
-  if (j > 0 && edge_bucket[j - 1] == b) return;
-  const uint4* src = reinterpret_cast<const uint4*>(edges + (size_t)j * proj_words<C>());
-  uint4* dst = reinterpret_cast<uint4*>(buckets + (size_t)b * proj_words<C>());
-#pragma unroll
-  for (int k = 0; k < proj_words<C>() / 4; ++k) dst[k] = src[k];
-}
-
 // the VM's addition as a real call: its registers are then not part of the caller's allocation (the rare equal-points case of the
 // two-lane addition: inlined, the three-lane kernels spilled 500 registers and the step ran 2.4x slower than through the VM; the tree
 // level of the edge merge: see there)
@@ -1434,7 +1345,8 @@ template <class C>
 __device__ __attribute__((noinline)) void pt_vm_add_outlined(Proj<C>& P, const Proj<C>& Q, int pc) { pt_vm<C, true>(P, Q, pc); }
 
 // ---- edge merge as a tree over the lanes of a bucket (round 4) -----------------------------------------------------------------------
-// The pointer-jumping merge above is general but pays for it: 2 log2(slots) dependent launches (34 for 65536 lanes: a sum into a
+// The pointer-jumping merge of rounds 1-3 (every slot adds the slot 2^s further on if it belongs to the same bucket; out of the
+// product since round 5) was general but paid for it: 2 log2(slots) dependent launches (34 for 65536 lanes: a sum into a
 // temporary and a copy back per level), every one of them over ALL slots, and half the partners are the identity pieces that keep the
 // slot list gap-free.  But where the pieces of a bucket are is no secret: bucket b holds the entries [o0, o1) of the list, lane t walks
 // the entries [t T, (t + 1) T), so b has one piece in each of the lanes t_lo = o0 / T .. t_hi = (o1 - 1) / T -- the last run of lane t_lo
@@ -1442,7 +1354,7 @@ __device__ __attribute__((noinline)) void pt_vm_add_outlined(Proj<C>& P, const P
 // t_lo + i.  A tree over i, IN PLACE: at level l (stride S = K^l) the piece with i % (K S) == 0 adds the pieces i + S, i + 2 S, .. into
 // its own slot; after ceil(log_K(pieces)) levels piece 0 holds the bucket.  No temporary, no copy, every piece read once per level it
 // takes part in, a bucket inside one lane costs nothing, the common bucket (two lanes) one addition; the levels after the last useful
-// one leave at once (a device flag, as above).  K = 2: one addition deep per level, log2(lanes) launches (half the old count).  K = 8
+// one leave at once.  K = 2: one addition deep per level, log2(lanes) launches (half the old count).  K = 8
 // (six launches) was measured first and lost wherever buckets span several lanes -- its K - 1 additions per level run one after the
 // other in one lane: MNT6753 G1 2^13 points with c = 14 (54 entries per bucket over ~7 lanes) 1.16 ms with pointer jumping, 3.9 ms with
 // K = 8 (profiles/r04/small_msm_window_width_k8_tree.txt) -- and a witness full of ones puts half the list into one bucket.
@@ -1454,40 +1366,6 @@ __device__ __forceinline__ uint32_t acc_entries_per_lane(uint32_t T, uint32_t n_
 // slot of the piece lane t holds of the bucket that starts at entry o0 in lane t_lo
 __device__ __forceinline__ uint32_t edge_piece_slot(uint32_t t, uint32_t t_lo, uint32_t o0, uint32_t T) {
   return (t == t_lo && (uint64_t)o0 > (uint64_t)t_lo * T) ? 2u * t + 1u : 2u * t;
-}
-template <class C>
-__global__ void __launch_bounds__(256, vm_waves<C>()) k_edge_tree_level(uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
-                                                           const uint32_t* __restrict__ offsets, uint32_t n_buckets, uint32_t T_arg, uint32_t n_lanes,
-                                                           uint32_t blocked, uint32_t stride, uint32_t* __restrict__ flags, uint32_t level) {
-  if (level > 0 && flags[level - 1] == 0) return;   // no bucket spans more than `stride` lanes: nothing left to do
-  const uint32_t sidx = logical_lane<typename C::F>();
-  if (sidx >= 2u * n_lanes) return;
-  const uint32_t b = edge_bucket[sidx];
-  if (b == EDGE_NONE) return;
-  const uint32_t T = acc_entries_per_lane(T_arg, n_lanes, offsets[n_buckets], blocked != 0);
-  const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
-  const uint32_t t = sidx >> 1, t_lo = o0 / T, t_hi = (o1 - 1u) / T;
-  if (t_hi == t_lo || edge_piece_slot(t, t_lo, o0, T) != sidx) return;   // a bucket inside one lane; the identity filler of a one-run lane
-  const uint32_t i = t - t_lo, k = t_hi - t_lo + 1u;
-  // The thread of piece i works as NODE i of this level: it sums the pieces K S i, K S i + S, .. into the first of them.  (A relabelling:
-  // "piece i works if i % (K S) == 0" is the same tree, but leaves one working lane in 2 K S slots -- from the third level on every
-  // wave over a long bucket carries a single addition and a level costs what the first one did; with the nodes packed at the front of
-  // the bucket's lane range the waves stay full and their number halves per level.)
-  const uint64_t group = (uint64_t)stride * EDGE_TREE_K, first = (uint64_t)i * group;
-  if (first + stride >= k) return;    // no such node, or a node of one piece
-  const uint32_t dst = edge_piece_slot(t_lo + (uint32_t)first, t_lo, o0, T);
-  Proj<C> acc, Q;
-  proj_load<C>(acc, edges + (size_t)dst * proj_words<C>());
-  for (uint32_t j = 1; j < EDGE_TREE_K; ++j) {
-    const uint64_t ii = first + (uint64_t)j * stride;
-    if (ii >= k) break;
-    const uint32_t slot = edge_piece_slot(t_lo + (uint32_t)ii, t_lo, o0, T);
-    proj_load<C>(Q, edges + (size_t)slot * proj_words<C>());
-    const int pc = add_pc<C>(acc, Q);
-    pt_vm_add_outlined<C>(acc, Q, pc);
-  }
-  proj_store<C>(edges + (size_t)dst * proj_words<C>(), acc);
-  if (i == 0 && (uint64_t)k > group) flags[level] = 1;   // this bucket needs another level
 }
 // piece 0 of every bucket that left pieces in the edge slots now holds its sum
 template <class C>
@@ -1727,31 +1605,6 @@ __global__ void __launch_bounds__(256, 1) k_reduce_step_pair(const uint32_t* __r
   pt_add_pairlanes<C>(out, S, T, odd, g.partner4);
   if (odd || !live) return;
   proj_store<C>(dst, out);
-}
-// Edge merge level with two point-lanes per addition (same addition core): slot j adds slot j + dist when both belong to one bucket.
-template <class C>
-__global__ void __launch_bounds__(256, 1) k_edge_level_sum_pair(const uint32_t* __restrict__ edges, const uint32_t* __restrict__ edge_bucket,
-                                                               uint32_t* __restrict__ tmp, uint32_t n_slots, uint32_t dist,
-                                                               uint32_t* __restrict__ flags, uint32_t level) {
-  using F = typename C::F;
-  if (level > 0 && flags[level - 1] == 0) return;   // wave-uniform: nothing left to do
-  const PairGeom<F> g = pair_geometry<F>();
-  const uint32_t j = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PairGeom<F>::PAIRS_PER_WAVE + g.pair_in_wave;
-  bool act = g.valid && j < n_slots && j + dist < n_slots;
-  uint32_t b = EDGE_NONE;
-  if (act) { b = edge_bucket[j]; act = b != EDGE_NONE && edge_bucket[j + dist] == b; }
-  // a wave none of whose pairs has work leaves together; otherwise every lane runs the addition (the exchanges need the partner)
-  if (__ballot(act) == 0ull) return;
-  constexpr int PW = proj_words<C>();
-  const uint32_t jj = act ? j : 0u;
-  const uint32_t iS = g.odd ? jj + dist : jj, iT = g.odd ? jj : jj + dist;
-  Proj<C> S, T, out;
-  if (act) { proj_load<C>(S, edges + (size_t)iS * PW); proj_load<C>(T, edges + (size_t)iT * PW); }
-  else { pt_set_zero(S); pt_set_zero(T); }
-  pt_add_pairlanes<C>(out, S, T, g.odd, g.partner4);
-  if (g.odd || !act) return;
-  proj_store<C>(tmp + (size_t)j * PW, out);
-  flags[level] = 1;
 }
 // out = P + Q, one lane per addition without the VM: operator+ of the reference (mnt4753_g1.cpp:134-207: add-1998-cmo-2, 12 products
 // + 2 squarings) in a straight line; identities pass through, equal points fall back to the VM (whose addition turns into its doubling).

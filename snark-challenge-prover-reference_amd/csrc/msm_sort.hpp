@@ -1,4 +1,4 @@
-// Radix-sort variant of an MSM's sort stage (msm_sort.hip): group-independent, shared by the four instantiation units.
+// The device-wide sort stage of an MSM (msm_sort.hip): group-independent, shared by the four instantiation units.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -6,12 +6,7 @@
 #include "msm_types.hpp"
 
 namespace mnt753 {
-size_t msm_sort_temp_bytes(size_t total);
-int msm_sort_radix(int frm, const uint32_t* d_scal, const uint8_t* d_inf, size_t n, const MsmPlan& p, uint32_t entry_stride, uint32_t entry_base,
-                   uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, void* tmp, size_t tmp_bytes, uint32_t* dense,
-                   uint32_t* d_hist, uint32_t* d_offsets, uint32_t* d_cursor, uint32_t* d_blocksums, uint32_t* d_total, uint32_t* d_sorted,
-                   hipStream_t st);
-// hand-written two-level counting sort (round 3): same outputs (d_offsets, padded d_sorted; d_hist ends as the bucket counts)
+// hand-written two-level counting sort (round 3): d_offsets, padded d_sorted; d_hist ends as the bucket counts
 int msm_sort_partition(int frm, const uint32_t* d_scal, const uint8_t* d_inf, size_t n, const MsmPlan& p, uint32_t entry_stride, uint32_t entry_base,
                        uint32_t* keys_out, uint32_t* vals_out, uint32_t* part_ws, uint32_t* d_hist, uint32_t* d_offsets, uint32_t* d_cursor,
                        uint32_t* d_blocksums, uint32_t* d_total, uint32_t* d_sorted, hipStream_t st);

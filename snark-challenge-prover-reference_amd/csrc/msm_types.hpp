@@ -34,11 +34,7 @@ struct mnt753_bases {
   uint32_t* d_rank = nullptr;   // rank of every (window, scalar) entry inside its bucket (returned by the histogram atomics)
   uint32_t *d_hist = nullptr, *d_offsets = nullptr, *d_cursor = nullptr, *d_blocksums = nullptr, *d_total = nullptr;
   uint32_t* d_sorted = nullptr;
-  // radix-sort variant of the sort stage (msm_sort.hip; large inputs): sorted (key, value) pairs, rocPRIM's temporary storage,
-  // first index of every bucket in the sorted keys
-  uint32_t *d_keys_out = nullptr, *d_vals_out = nullptr, *d_dense = nullptr;
-  void* d_sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
+  uint32_t *d_keys_out = nullptr, *d_vals_out = nullptr;   // (key, value) pairs of the two-level counting sort, partition order
   uint32_t* d_part_ws = nullptr;   // partition totals / starts / cursors of the two-level counting sort (msm_sort_partition)
   uint32_t *d_buckets = nullptr, *d_edges = nullptr, *d_edge_bucket = nullptr, *d_edge_tmp = nullptr, *d_edge_flags = nullptr;
   uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;

@@ -1,4 +1,4 @@
-// ./main_hip <curve> compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--fold rccl|host] [--point-cus N] [--unfused-h] [--unfused-c] [--ref-order] [--quiet]
+// ./main_hip <curve> compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--fold rccl|host] [--unfused-h] [--unfused-c] [--ref-order] [--quiet]
 //            --serve: keep the parameters resident and prove further "<input> <output>" pairs read from stdin, one per line
 // ./main_hip <curve> compute-r1cs <params> <r1cs> <witness> <output> ...      (ca / cb / cc evaluated on the device from the constraint system)
 // ./main_hip <curve> complete <keys> <input|witness> <challenge_proof> <full_proof> [--s-file <Fr> | --s-seed N]
@@ -38,7 +38,6 @@ static bool g_fused_c = true;   // C = Ht + Lt + r Bt1 as one MSM over H | L | B
 static int g_gpus = 0;   // --gpus N: parameter vectors sharded over N devices of this node (0: MNT753_GPUS or 1)
 static bool g_serve = false;    // --serve: after the listed jobs, read further "<input> <output>" lines from stdin until EOF
 static int g_fold_rccl = -1;    // --fold rccl | host: where the partial points of a sharded multiexp meet (default: MNT753_FOLD, else host)
-static int g_point_cus = 256;   // --point-cus N: CUs the point kernels are sized for (include/mnt753_hip.h, mnt753_msm_set_point_cus)
 
 typedef std::chrono::steady_clock clk;
 static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
@@ -164,7 +163,6 @@ void prove_one(typename B::groth16_params* params, const char* input_path, const
 template <typename B>
 void run_prover(const char* params_path, const std::vector<std::pair<std::string, std::string>>& jobs, const char* r1cs_path = nullptr) {
   if (g_gpus > 0) B::use_devices(g_gpus);
-  (void)mnt753_msm_set_point_cus(g_point_cus);
   B::fuse_C(g_fused_c);
   if (g_fold_rccl >= 0) B::fold_over_rccl(g_fold_rccl != 0);
   B::init_public_params();
@@ -284,7 +282,6 @@ int main(int argc, char** argv) {
   for (int i = a0 + 2; i < argc; ++i) {
     if (!strcmp(argv[i], "--repeat") && i + 1 < argc) { repeat = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { g_gpus = atoi(argv[++i]); continue; }
-    if (!strcmp(argv[i], "--point-cus") && i + 1 < argc) { g_point_cus = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--fold") && i + 1 < argc) { g_fold_rccl = !strcmp(argv[++i], "rccl") ? 1 : 0; continue; }
     if (argv[i][0] != '-' && i + 1 < argc && argv[i + 1][0] != '-') { jobs.emplace_back(argv[i], argv[i + 1]); ++i; continue; }
     if (!strcmp(argv[i], "--fused-h")) g_fused_h = true;

@@ -27,6 +27,16 @@ namespace mnt753_hip_detail {
   throw std::runtime_error(std::string(what) + ": " + mnt753_last_error());
 }
 static void check(int rc, const char* what) { if (rc != 0) fail(what); }
+static bool trace_on() { const char* e = getenv("MNT753_TRACE"); return e && atoi(e) != 0; }
+// MNT753_TRACE=1: where the seconds of a parameter load go (file reads, base sets with their window tables, domains, warm-up)
+struct LoadTrace {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    const auto t1 = std::chrono::steady_clock::now();
+    if (trace_on()) fprintf(stderr, "mnt753: load params: %-46s %7.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 // Per-proof vectors (w, ca, cb, cc, coefficients_for_H, the per-device slices) have the same sizes proof after proof, and both
 // hipMalloc and hipFree are expensive where it hurts: four 100 MB hipMallocs open the reference's timing window (1 ms on an idle box,
@@ -265,14 +275,19 @@ public:
     off_H = off_L + 8 * g1w * (m - 1);
     const bool fused = fused_c();
     std::vector<uint64_t> host, cat;
+    LoadTrace lt;
     auto load = [&](int group, size_t words, size_t n, size_t cat_at) {
       host.resize(words * n);
       read_exact(f, host.data(), host.size() * 8, path_);
       if (fused && group == MNT753_G1 && cat_at != (size_t)-1) {   // a part of the concatenated set: keep the host copy, no set of its own
         memcpy(cat.data() + g1w * cat_at, host.data(), host.size() * 8);
+        lt.lap("read a part of H | L | B1 from the file");
         return std::shared_ptr<ShardedBases>();
       }
-      return make_set(group, words, n, host.data());
+      lt.lap(group == MNT753_G1 ? "read A from the file" : "read B2 from the file");
+      auto set = make_set(group, words, n, host.data());
+      lt.lap(group == MNT753_G1 ? "base set A (upload, window table, workspace)" : "base set B2 (upload, window table, workspace)");
+      return set;
     };
     if (fused) cat.resize(g1w * (d + 2 * m));
     try {
@@ -281,7 +296,7 @@ public:
       B2 = load(MNT753_G2, g2w, m + 1, (size_t)-1);
       L = load(MNT753_G1, g1w, m - 1, d);
       H = load(MNT753_G1, g1w, d, 0);
-      if (fused) HLB = make_hlb_set(g1w, cat);
+      if (fused) { HLB = make_hlb_set(g1w, cat); lt.lap("base set H | L | B1 (upload, window table, workspace)"); }
     } catch (...) { fclose(f); throw; }
     fclose(f);
   }
@@ -825,13 +840,9 @@ static void compact_in_rank_order(PendingMsm& pm) {
 // Measured (profiles/r04/prove_msm_order.txt, alternating on one box): MNT6753 2^15 15.7 -> 15.2 ms in one series, 15.3 -> 15.2 in a
 // second; MNT4753 2^20 157.2 -> 158.4 ms
 // -- there the two MSMs interleaved fill each other's kernel ends, which is worth more than a hidden 3 ms tail -- so only the small
-// sets are ordered (C over at most 2^18 points on the device).  MNT753_ORDER_MSMS=0: never, =2: always.
-static int order_msms() {
-  static const int mode = getenv("MNT753_ORDER_MSMS") ? atoi(getenv("MNT753_ORDER_MSMS")) : 1;
-  return mode;
-}
+// sets are ordered (C over at most 2^18 points on the device).
 static void gate_set(int g, mnt753_bases* c) {
-  if (order_msms() == 0 || (order_msms() != 2 && mnt753_bases_size(c) > ((size_t)1 << 18))) return;
+  if (mnt753_bases_size(c) > ((size_t)1 << 18)) return;
   if (g_gate.size() <= (size_t)g) g_gate.resize((size_t)g + 1, nullptr);
   g_gate[(size_t)g] = c;
 }
@@ -856,10 +867,9 @@ static std::shared_ptr<PendingMsm> start_sharded(ShardedBases& sb, const ScalarS
       check(mnt753_copy_peer_async(g, part.scalars->ptr, src.home, src.home_ptr() + 12 * lo, 96 * (hi - lo)), "mnt753_copy_peer_async");
       sc = reinterpret_cast<const uint64_t*>(part.scalars->ptr);
     }
-    // mode 4 (development): every MSM of a small set behind the one started before it on the device (G2 -> C -> A), not only A behind C
-    if (!is_c || order_msms() == 4) gate_apply(g, part.set->h);
+    if (!is_c) gate_apply(g, part.set->h);
     check(mnt753_msm_start(part.set->h, 0, sc, 1, hi - lo, nullptr), what);
-    if (is_c || (order_msms() == 4 && mnt753_bases_size(part.set->h) <= ((size_t)1 << 18))) gate_set(g, part.set->h);
+    if (is_c) gate_set(g, part.set->h);
     pend->sets[(size_t)g] = part.set;
   }
   // rank order for the fold (multiexp.tcc:433-438), whatever the order of enqueueing was
@@ -1078,10 +1088,13 @@ template <int CURVE> static void warm_up(typename mnt753_hip_impl<CURVE>::groth1
 template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const char* path) {
   groth16_params* p = new groth16_params(path);
   const int n_dev = std::max(1, mnt753_device_count());
+  LoadTrace lt;
   auto dom = cached_domain<CURVE>(p->d + 1);
   // a sharded prover transforms cb on device 1 and cc on device 2 (groth16_input): their tables are built now, like device 0's
   for (int g = 1; g < std::min(n_dev, 3); ++g) (void)cached_domain<CURVE>(p->d + 1, g);
+  lt.lap("evaluation domain(s): twiddle and coset tables");
   warm_up<CURVE>(p);
+  lt.lap("warm-up MSM per base set");
   // the buffers of one proof, allocated now and parked in the cache: w, ca, cb, cc, coefficients_for_H, the scalars of groth16_C, and
   // with several devices each device's range of w, its vector of compute_H and the staging of the transformed cb / cc on device 0
   {

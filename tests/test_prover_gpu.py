@@ -30,12 +30,13 @@ def test_reference_proof_files(gpu, curve, flags, tmp_path):
 
 
 @pytest.mark.parametrize("curve", [0, 1])
-@pytest.mark.parametrize("env", [{"MNT753_REDUCE_PAIR": "0"}, {"MNT753_REDUCE_LINE": "0"}, {"MNT753_REDUCE_PAIR": "0", "MNT753_REDUCE_LINE": "0"},
-                                 {"MNT753_REDUCE_PAIR_MAX": "100000000"}, {"MNT753_MSM_SORT": "atomic"}, {"MNT753_MSM_SORT": "radix"}, {"MNT753_MSM_SORT": "part"},
-                                 {"MNT753_MSM_SORT": "part", "MNT753_MSM_PAIR": "2"}, {"MNT753_EDGE_PAIR": "0"}])
+@pytest.mark.parametrize("env", [{"MNT753_MSM_SORT": "atomic"}, {"MNT753_MSM_SORT": "part"}, {"MNT753_MSM_SORT": "part", "MNT753_MSM_PAIR": "2"},
+                                 {"MNT753_EDGE_FLOW_NODES": "0"}, {"MNT753_EDGE_FLOW_NODES": "100000000"}, {"MNT753_MSM_TMIN": "1"},
+                                 {"MNT753_MSM_PAIR": "3", "MNT753_MSM_IRR": "2"}, {"MNT753_MSM_PRECOMP": "0"}])
 def test_alternative_kernel_paths_write_the_same_proof(gpu, curve, env, tmp_path):
-    """The bucket reduction has three addition kernels (the VM's, two lanes per addition, straight-line) and the sort stage two
-    variants; the environment switches between them and every combination must reproduce the reference's proof bytes."""
+    """The switches the product keeps (round 5 pruned the measured-and-rejected variants): both sort stages, pairing / irregular levels
+    forced onto these small sets, every level of the edge merge through the VM form or through lane groups, one entry per accumulate
+    lane, no window table.  Every one must reproduce the reference's proof bytes."""
     params, inp, expected = G.e2e_paths(curve)
     out = str(tmp_path / "proof.bin")
     r = subprocess.run([EXE, NAME[curve], "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, **env))

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """GPU box: MSM time at the per-device sizes an N-way split of the benchmark configurations produces, by pairing-level count
-and batch-length floor -- the data behind pair_levels() / PAIR_MIN_B in csrc/msm_host.hpp and behind the predicted 1/2/4/8-GPU
+-- the data behind pair_levels() in csrc/msm_host.hpp (the batch-length floor PAIR_MIN_B = 8 was settled by this sweep in round 3) and behind the predicted 1/2/4/8-GPU
 curve in DESIGN.md section 5 (multiexp.tcc:417-440 splits ONE array into contiguous slices; slice g runs the whole Pippenger).
 
     python tools/slice_sweep.py [--quick] [--out gpurun_out/slice_sweep.json]
 
-For every (curve, group, log2 n): the default plan, then MNT753_MSM_PAIR in {0, 1, 2, 3} x MNT753_PAIR_MINB in {8, 48}.
+For every (curve, group, log2 n): the default plan, then MNT753_MSM_PAIR in {0, 1, 2, 3, 4}.
 Every result is checked through the discrete logs of the synthetic bases (synth_expected_msm)."""
 import argparse
 import json
@@ -42,9 +42,9 @@ def main():
         dsc = pkg.DeviceBuffer.from_numpy(sc)
         variants = [(None, None)]
         if not args.quick:
-            variants += [(lv, mb) for lv in (0, 1, 2, 3, 4) for mb in ((8, 48) if lv else (None,))]
+            variants += [(lv, None) for lv in (0, 1, 2, 3, 4)]
         for lv, mb in variants:
-            for k, v in (("MNT753_MSM_PAIR", lv), ("MNT753_PAIR_MINB", mb)):
+            for k, v in (("MNT753_MSM_PAIR", lv),):
                 if args.quick:
                     break            # --quick: whatever the environment says (tools/experiments/*.sh set the knobs themselves)
                 if v is None:
@@ -65,7 +65,7 @@ def main():
                        table=plan["window_table"], ok=ok, **{k: round(v, 3) for k, v in best.items()})
             rows.append(row)
             print(json.dumps(row), flush=True)
-        os.environ.pop("MNT753_MSM_PAIR", None); os.environ.pop("MNT753_PAIR_MINB", None)
+        os.environ.pop("MNT753_MSM_PAIR", None)
         bs.close(); dsc.close()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:

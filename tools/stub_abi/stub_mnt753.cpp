@@ -125,7 +125,6 @@ int mnt753_msm(mnt753_bases* b, size_t off, const uint64_t* sc, int od, size_t n
   return mnt753_msm_finish(b, out);
 }
 int mnt753_msm_set_window_bits(int) { return 0; }
-int mnt753_msm_set_point_cus(int) { return 256; }
 int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first) { return (b && first && b != first) ? 0 : 22; }
 int mnt753_msm_last_timing(float o[5]) { for (int i = 0; i < 5; ++i) o[i] = 0; return 0; }
 int mnt753_msm_last_plan(int o[4]) { for (int i = 0; i < 4; ++i) o[i] = 0; return 0; }
