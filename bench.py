@@ -315,7 +315,12 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
         t0 = time.time()
         # `repeat` proofs of the same input in ONE process: the first is the reference's metric (fresh process, parameters loaded,
         # then input -> output); the others show what a resident prover pays per proof
-        r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", str(repeat)] + dev_flags, capture_output=True, text=True, env=child_env)
+        # (every prover child under a timeout: a hang on hardware this builder never saw -- several real GPUs -- must cost one leg, not the run)
+        try:
+            r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", str(repeat)] + dev_flags, capture_output=True, text=True, env=child_env, timeout=900)
+        except subprocess.TimeoutExpired:
+            out.update(error="main_hip did not finish within 900 s", parity_ok=False)
+            return out, cpu_out
         wall = time.time() - t0
         if r.returncode != 0:
             out.update(error=r.stderr[-400:], parity_ok=False)
@@ -355,7 +360,11 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
                 if os.path.exists(q):
                     os.remove(q)
             t0 = time.time()
-            r2 = subprocess.run([exe, curve_name, "compute", pp, ip, op] + flags + dev_flags, capture_output=True, text=True, env=dict(child_env, **env_extra))
+            try:
+                r2 = subprocess.run([exe, curve_name, "compute", pp, ip, op] + flags + dev_flags, capture_output=True, text=True, env=dict(child_env, **env_extra), timeout=600)
+            except subprocess.TimeoutExpired:
+                out[key] = {"error": "main_hip did not finish within 600 s"}
+                continue
             if r2.returncode != 0:
                 out[key] = {"error": r2.stderr[-300:]}
                 continue
@@ -365,6 +374,13 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
                         "same_bytes": sha2 == sha, "note": note}
             if key == "fold_rccl":
                 out[key]["folded"] = "over RCCL" if "over RCCL" in r2.stderr else ("on the host (no communicator: " + ("logical devices share a GPU" if share else "librccl unavailable") + ")")
+                # what the box granted for the device pairs the sharded prover copies between (one MNT753_TRACE line per ordered pair)
+                pairs = [l for l in r2.stderr.splitlines() if l.startswith("mnt753: device ") and " reads device " in l]
+                out["peer_access"] = {"ordered_pairs": len(pairs), "direct": sum("direct" in l for l in pairs), "staged_through_host": sum("staged" in l for l in pairs),
+                                      "same_gpu": sum("same GPU" in l for l in pairs)}
+                lat = [float(m) for m in re.findall(r"devices in ([0-9.]+) us", r2.stderr)]
+                if lat:
+                    out[key]["all_gather_us"] = {"first": lat[0], "min": min(lat), "calls": len(lat)}
             if sha2 != sha:
                 out["parity_ok"] = False
         if cpu:

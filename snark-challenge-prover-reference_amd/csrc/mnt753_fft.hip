@@ -99,7 +99,8 @@ int run_stages(mnt753_domain* d, uint32_t* vec, const uint32_t* tw, hipStream_t 
     const uint32_t* is = gi == 0 ? in_scale : nullptr;
     const uint32_t* os = gi == n_groups - 1 ? out_scale : nullptr;
     const int bitrev = gi == 0 ? 1 : 0;
-    if (is && os) hipLaunchKernelGGL((k_ntt_group<M, true, true>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, bitrev, is, os);
+    // (no transform of the path scales on both sides: callers pass in_scale or out_scale, never both)
+    if (is && os) return set_error(MNT753_EINVAL, "ntt: a transform scales on the way in or on the way out, not both");
     else if (is) hipLaunchKernelGGL((k_ntt_group<M, true, false>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, bitrev, is, os);
     else if (os) hipLaunchKernelGGL((k_ntt_group<M, false, true>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, bitrev, is, os);
     else hipLaunchKernelGGL((k_ntt_group<M, false, false>), dim3(blocks), dim3(NTT_BLOCK), 0, st, src, dst, tw, logm, s0, ns, bitrev, is, os);

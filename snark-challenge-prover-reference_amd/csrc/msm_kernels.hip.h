@@ -655,12 +655,12 @@ __device__ __forceinline__ void fp_store_blk(uint4* __restrict__ base, uint32_t 
 constexpr uint32_t PAIR_IMG_QUADS = 1792;                       // 2 points x 64 lanes x 14 quads (every field: NS * RQ * 2 <= 1792)
 constexpr uint32_t PAIR_LDS_WAVE_QUADS = PAIR_IMG_QUADS + 448 + 128;  // rows, prefix product, entries (4 x 128 u32)
 constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
-// EXPERIMENT (round 5, default off): first level of a base field, every LDS-DMA instruction fetches WHOLE rows -- 4 rows x 14 quads
-// (56 lanes) of a full-row image, 9 rows x 7 quads (63 lanes) of an x image -- instead of 64 consecutive quads of the packed image,
-// which cross rows (4.6 rows per instruction, every lane dividing by 14 to find its row).  The image layout is unchanged.
-#ifndef MNT753_EXP_WHOLE_ROWS
-#define MNT753_EXP_WHOLE_ROWS 0
-#endif
+// (Round 5 measured the other cut of the first level's LDS-DMA pieces: every instruction fetching WHOLE rows -- 4 rows x 14 quads on 56
+// lanes of a full-row image, 9 rows x 7 quads on 63 lanes of an x image -- instead of 64 consecutive quads of the packed image, which
+// cross rows (4.6 rows per instruction, every lane dividing by 14 to find its row).  Simpler addresses (121 fewer VALU instructions in
+// the kernel, 162 fewer register moves), 32 + 15 instructions per slot instead of 28 + 14, some lanes idle: level 1 of the 2^20 G1 MSM
+// 11.08 / 11.15 / 11.30 ms packed against 11.69 / 11.70 / 11.67 ms whole rows, alternating on one box
+// (profiles/r05/level1_whole_row_pieces.txt) -- the number of DMA instructions is what the wave pays for, not their address arithmetic.)
 // portions the LDS-DMA of the next slot's image is issued in, one ahead of each of the first products of a slot: gathered rows of a
 // base field in four, of the lane-split fields in five, own planes in three (profiles/r03/ab_first_level_dma_portions.txt)
 constexpr uint32_t PAIR_DMA_STEPS_FIRST = 4, PAIR_DMA_STEPS_LATER = 3;
@@ -859,12 +859,6 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   auto irr_word = [=](uint32_t it) __attribute__((always_inline)) {
     return irr_src[min(it * NLe + (lane_on ? t : t0w), S - 1u)];
   };
-  // whole-row pieces (experiment): rows per instruction, quads of the image per instruction, this lane's row and quad inside a piece
-  constexpr bool WR = first && LN == 1 && MNT753_EXP_WHOLE_ROWS;
-  constexpr uint32_t WR_ROWS = 64u / RQ, WR_ROWS_X = 64u / XQ;                 // 4 and 9 for a base field
-  constexpr uint32_t DQ = WR ? WR_ROWS * RQ : 64u, DQX = WR ? WR_ROWS_X * XQ : 64u;
-  const uint32_t wr_j = min(lane / RQ, WR_ROWS - 1u), wr_q = lane - (lane / RQ) * RQ, wr_jx = lane / XQ, wr_qx = lane - (lane / XQ) * XQ;
-  const bool wr_on = lane < DQ;
   auto issue_row_piece = [=](uint32_t it, uint32_t buf, uint32_t k, auto xonly_c, uint4* im, uint32_t sw = 0u) __attribute__((always_inline)) {
     constexpr bool xonly = decltype(xonly_c)::value;
     if constexpr (IRR) {
@@ -872,14 +866,6 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       irr_bases(sw, va, vb);
       const uint32_t pl = k / 7u, q = k - pl * 7u;        // image planes: x1 | x2 | y1 | y2
       glds16(src_planes + (size_t)(pl & 2u) * src_stride + (size_t)q * 64 + ((pl & 1u) ? vb : va), im + k * 64u);
-    } else if constexpr (WR) {
-      constexpr uint32_t rows = xonly ? WR_ROWS_X : WR_ROWS, dq = xonly ? DQX : DQ;
-      const uint32_t rs = rows * k + (xonly ? wr_jx : wr_j);
-      if (lane < dq && rs < 2u * NS) {
-        const uint32_t e = ent_img[buf * 128u + 2u * (rs & (NS - 1u)) + (rs >= NS ? 1u : 0u)];
-        const uint32_t r = e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu);
-        glds16(table + (size_t)r * RQ + (xonly ? wr_qx : wr_q), im + dq * k);
-      }
     } else if constexpr (first) {
       constexpr uint32_t rq = xonly ? XQ : RQ;
       constexpr uint32_t total = 2u * NS * rq;
@@ -896,8 +882,8 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       glds16(src_planes + blk_index(j) + (size_t)pl * src_stride + (size_t)q * 64, im + k * 64u);
     }
   };
-  constexpr uint32_t ROW_PIECES_X = first ? (WR ? (2u * NS + WR_ROWS_X - 1u) / WR_ROWS_X : (2u * NS * XQ + 63u) / 64u) : 14u;
-  constexpr uint32_t ROW_PIECES = first ? (WR ? (2u * NS + WR_ROWS - 1u) / WR_ROWS : (2u * NS * RQ + 63u) / 64u) : 28u;
+  constexpr uint32_t ROW_PIECES_X = first ? (2u * NS * XQ + 63u) / 64u : 14u;
+  constexpr uint32_t ROW_PIECES = first ? (2u * NS * RQ + 63u) / 64u : 28u;
   auto issue_rows = [=](uint32_t it, uint32_t buf, auto xonly_c, uint4* im, uint32_t sw = 0u) __attribute__((always_inline)) {
     constexpr uint32_t n = decltype(xonly_c)::value ? ROW_PIECES_X : ROW_PIECES;
 #pragma unroll
@@ -907,13 +893,6 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   // A ds_read + s_waitcnt lgkmcnt(0) in front of EVERY LDS-DMA instruction cost a quarter of the level (the LDS queue is
   // busy with the DMA's own writes); the offsets of the next slot now sit in registers before the first piece is issued.
   auto row_offset = [=](uint32_t buf, uint32_t k) __attribute__((always_inline)) {      // piece k of a full-row image
-    if constexpr (WR) {
-      // rows WR_ROWS k .. WR_ROWS k + 3 never straddle the two points of the image (NS is a multiple of WR_ROWS): the entry index is a
-      // constant of the piece plus a constant of the lane
-      const uint32_t r0 = WR_ROWS * k;
-      const uint32_t e = ent_img[buf * 128u + (2u * (r0 & (NS - 1u)) + (r0 >= NS ? 1u : 0u)) + 2u * wr_j];
-      return (e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu)) * RQ + wr_q;
-    }
     const uint32_t i = min(64u * k + lane, 2u * NS * RQ - 1u);
     const uint32_t rs = i / RQ, q = i - rs * RQ;
     const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
@@ -927,12 +906,6 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     constexpr uint32_t n = xonly ? ROW_PIECES_X : ROW_PIECES;
 #pragma unroll
     for (uint32_t k = 0; k < n; ++k) {
-      if constexpr (WR && xonly) {
-        const uint32_t rs = min(WR_ROWS_X * k + wr_jx, 2u * NS - 1u);
-        const uint32_t e = ent_img[buf * 128u + 2u * (rs & (NS - 1u)) + (rs >= NS ? 1u : 0u)];
-        off[k] = (e == ENTRY_EMPTY ? 0u : PAIR_ROW(e & 0x7fffffffu)) * RQ + wr_qx;
-        continue;
-      }
       const uint32_t i = min(64u * k + lane, total - 1u);
       const uint32_t rs = i / rq, q = i - rs * rq;
       const uint32_t p = rs >= NS ? 1u : 0u, s = rs - p * NS;
@@ -965,7 +938,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   PAIR_T(tc0);
   PAIR_TW_DECL(tw_a); PAIR_TW_DECL(tw_b); PAIR_TW_DECL(tw_c); PAIR_TW_DECL(tw_d);
   constexpr uint32_t XIMG = PAIR_IMG_QUADS / 2u;          // one x-only image (14 pieces of 64 quads)
-  static_assert(WR || ROW_PIECES_X * 64u <= XIMG, "x image");
+  static_assert(ROW_PIECES_X * 64u <= XIMG, "x image");
   // x image of slot `it` -> half (it & 1) of the row image; first level: offsets from the entries in ent_img[it & 3]
   auto issue_x = [=](uint32_t it, uint32_t sw = 0u) __attribute__((always_inline)) {
     uint4* im = img + (it & 1u) * XIMG;
@@ -999,10 +972,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       if constexpr (first) issue_entries(min(it + AH + 1u, n_it - 1u), (it + AH + 1u) & 3u);
       if constexpr (PRELOAD) {
 #pragma unroll
-        for (uint32_t k = 0; k < ROW_PIECES_X; ++k) {
-          if constexpr (WR) { if (lane < DQX && WR_ROWS_X * k + wr_jx < 2u * NS) glds16(table + off[k], im + DQX * k); }
-          else glds16(table + off[k], im + 64u * k);
-        }
+        for (uint32_t k = 0; k < ROW_PIECES_X; ++k) glds16(table + off[k], im + 64u * k);
       } else {
         issue_rows(it + AH, (it + AH) & 3u, std::true_type{}, im, sw_nxt);
       }
@@ -1171,8 +1141,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
                 if constexpr (PRELOAD_BWD) {
                   uint32_t o = offp[u];
                   asm volatile("" : "+v"(o));
-                  if constexpr (WR) { if (wr_on) glds16(table + o, img + DQ * idx); }
-                  else glds16(table + o, img + 64u * idx);
+                  glds16(table + o, img + 64u * idx);
                 } else if constexpr (first) {
                   uint32_t k = idx;
                   asm volatile("" : "+s"(k));

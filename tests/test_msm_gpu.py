@@ -310,6 +310,29 @@ def O_point_scale(gpu, curve, aff, scalar):
     return gpu.api.point_scale(curve, 2, scalar, gpu.api.point_from_affine(curve, 2, aff))
 
 
+@pytest.mark.parametrize("group,n", [(1, 1 << 13), (2, 40000)])
+def test_wide_reduction_steps_of_the_mnt6753_groups(gpu, group, n, monkeypatch):
+    """Round 5, from the kernel-coverage list (profiles/r05/kernel_coverage.txt): the two instantiations no in-process test launched.
+    MNT6753 G1 with 8192 points takes 18-bit windows: the first halving steps of its 2^17 buckets are wide enough for the straight-line
+    addition (k_reduce_step_line<Mnt6G1>; the full-size proves reach it only inside main_hip).  MNT6753 G2 with 40 000 points takes
+    more buckets than one round of lane groups holds: its widest steps run the VM on the three-lane Fq3 (k_reduce_step<Mnt6G2S>), which
+    the benchmark sizes (at most 2^15 + 1 points: 14-bit windows) never do.  The G1 case also forces the two-level counting sort, whose
+    passes over the scalars of MNT6753 (k_part_pass<1, .>) the suite only ran on one workgroup.  Checked through the discrete logs of
+    the bases."""
+    if group == 1:
+        monkeypatch.setenv("MNT753_MSM_SORT", "part")
+    pts = gpu.synth_points(1, group, 4400 + group, n); sc = gpu.synth_scalars(1, 4500 + group, n)
+    sc[5] = 0; sc[6] = gpu.api.mont_one(1)
+    bs = gpu.BaseSet(1, group, pts)
+    try:
+        got = gpu.point_to_affine(1, group, bs.msm(sc))
+        plan = gpu.msm_last_plan()
+    finally:
+        bs.close()
+    assert plan["window_table"] and plan["window_bits"] >= (18 if group == 1 else 15), plan
+    assert np.array_equal(got, gpu.point_to_affine(1, group, gpu.synth_expected_msm(1, group, 4400 + group, sc)))
+
+
 def test_g2_lane_split_repeatable_at_sizes_that_faulted_with_dpp(gpu):
     """Regression: with a DPP quad_perm pair exchange k_bucket_reduce<Mnt4G2S> faulted / miscomputed at 2^16..2^19
     (never at 2^10..2^13); the exchange is ds_bpermute now.  Two runs per size must agree with the expectation."""
