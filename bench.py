@@ -333,8 +333,8 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
                    wall_incl_params_s=round(wall, 3), sha256=sha,
                    timing_window="libsnark/main.cpp:203-270 (input load + compute + output write; parameters resident)",
                    note=f"first of --repeat {repeat} in one process; B::read_params ends with one warm-up MSM per base set (parameter-load time, outside "
-                        "the window as in main.cpp:201-203): the reference's metric is a cold process, whose first proof pays page faults and code "
-                        "loading instead (0.23 s measured without the warm-up on an idle device)")
+                        "the window as in main.cpp:201-203); the reference's literal metric, the first proof of a process that has run nothing yet, is "
+                        "`cold_process` (MNT753_NO_WARMUP=1) beside it")
         m3 = re.findall(r"Total time from input to output: ([0-9.]+)s", r.stdout)
         if len(m3) > 1:
             out["input_to_output_s_all"] = [float(x) for x in m3]
@@ -355,10 +355,16 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
         if gpus > 1:
             side.append(("fold_rccl", ["--repeat", "2", "--fold", "rccl"], {"MNT753_TRACE": "1"},
                          "partial points through mnt753_exchange_points (ncclAllGather over the prover's devices) in front of the serial fold"))
+        # A prover that starts right behind another one waits for the driver to take back the ~100 GB the first one returned: measured on
+        # one box, parameter load 3.84 s first, 7.0 s right behind it, 3.85 s after a pause of 20 s -- and without the warm-up MSM that
+        # wait lands INSIDE the first proof (0.90 s against 0.18 s; profiles/r05/load_params_fresh_box.log).  Neither is the prover's:
+        # the side children start after a pause.
+        pause = 20.0 if log2_d >= 17 else 2.0
         for key, flags, env_extra, note in side:
             for q in (op,):
                 if os.path.exists(q):
                     os.remove(q)
+            time.sleep(pause)
             t0 = time.time()
             try:
                 r2 = subprocess.run([exe, curve_name, "compute", pp, ip, op] + flags + dev_flags, capture_output=True, text=True, env=dict(child_env, **env_extra), timeout=600)
@@ -371,7 +377,7 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
             ts, lp = _prover_times(r2.stdout)
             sha2 = sha256_file(op)
             out[key] = {"input_to_output_s": ts[0] if ts else None, "input_to_output_s_all": ts, "load_params_s": lp, "wall_incl_params_s": round(time.time() - t0, 3),
-                        "same_bytes": sha2 == sha, "note": note}
+                        "same_bytes": sha2 == sha, "pause_before_s": pause, "note": note}
             if key == "fold_rccl":
                 out[key]["folded"] = "over RCCL" if "over RCCL" in r2.stderr else ("on the host (no communicator: " + ("logical devices share a GPU" if share else "librccl unavailable") + ")")
                 # what the box granted for the device pairs the sharded prover copies between (one MNT753_TRACE line per ordered pair)
