@@ -1,0 +1,30 @@
+#!/bin/bash
+# round 5, GPU call D: the pairing levels behind the first at TWO waves per SIMD (csrc/msm_pair2w.hip.h, MNT753_EXP_PAIR2W=1) against
+# k_pair_level: parity (MSM tests that reach the levels, deep side paths), per-kernel times, the MSM as a whole; alternating on one box.
+mkdir -p gpurun_out/r5d
+export TMPDIR=/tmp
+O=$PWD/gpurun_out/r5d
+R=$PWD
+L=$R/build_exp/p2w/libmnt753_hip.so
+# parity first: the 2^20 / 2^19 MSMs through the discrete logs, skewed vectors, cancellations, forced levels on small sets
+( MNT753_LIB=$L MNT753_EXP_PAIR2W=1 timeout 900 python -m pytest tests/test_msm_gpu.py -m gpu -q -x -k "skewed or cancellation or pairing or randomized or full_size" ) > $O/pytest_p2w.log 2>&1
+echo "pytest (2 waves) rc=$?"; tail -3 $O/pytest_p2w.log | cut -c1-200
+for round in 1 2 3; do for v in one two; do
+  if [ $v = two ]; then export MNT753_EXP_PAIR2W=1; else unset MNT753_EXP_PAIR2W; fi
+  (cd /tmp && MNT753_LIB=$L timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2w_${v}_$round -o x -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-prove --no-extras --no-traffic --no-exchange > /tmp/p2w_${v}_$round.json 2>/dev/null)
+  python3 - /tmp/p2w_${v}_$round $v $round /tmp/p2w_${v}_$round.json <<'PY'
+import csv, glob, sys, json
+f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
+rows = [r for r in csv.DictReader(open(f[0])) if "k_pair_level" in r["Name"] or "k_bucket_accumulate" in r["Name"]]
+try:
+    j = json.load(open(sys.argv[4])); extra = f"ms_per_step {j['ms_per_step']:.3f} accumulate {j['phases_ms']['accumulate_ms']:.3f} parity {j['parity_ok']}"
+except Exception as ex:
+    extra = "bench line: " + repr(ex)[:80]
+print(f"== {sys.argv[2]} wave(s) per SIMD behind the first level, round {sys.argv[3]}: {extra}")
+for r in rows:
+    n = r["Name"].split("(")[0].replace("void mnt753::", "").replace("mnt753::", "")[:64]
+    print(f"     {n:64s} calls {r['Calls']:>3s} avg_ms {float(r['AverageNs'])/1e6:8.3f} total_ms {float(r['TotalDurationNs'])/1e6/8:8.3f} per MSM")
+PY
+done; done > $O/levels_two_waves_per_simd.txt 2>&1
+unset MNT753_EXP_PAIR2W
+cat $O/levels_two_waves_per_simd.txt
