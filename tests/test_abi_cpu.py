@@ -155,6 +155,17 @@ def test_window_table_doubling_compiled_for_the_host(tmp_path):
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_host_field_inversion(tmp_path):
+    """The host tails of the product (affine normalisation of the three results of a proof, the fold of partial points) invert through
+    host_field.hpp's binary extended Euclid (round 5; Fermat before).  Against libff's Fp_model::invert / Fp2_model / Fp3_model::inverse
+    (fp.tcc:641-685) through the minted vectors field_{A,B}.bin and extfield_mnt{4,6}.bin, and against Fermat on 4000 values per
+    modulus including 0, 1, p - 1, powers of two and single stored words."""
+    exe = tmp_path / "host_inv_check"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tools", "host_inv_check.cpp")], check=True, timeout=600)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.skipif(not os.path.isfile("/root/reference/cuda_prover_piecewise.cu"), reason="needs the reference tree (build container only)")
 def test_reference_driver_compiles_unchanged_against_the_hip_wrapper(tmp_path):
     """The drop-in claim of include/prover_hip_functions.hpp: compute_H<B>, run_prover<B> and main of the reference's

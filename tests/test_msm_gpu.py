@@ -274,6 +274,56 @@ def test_full_size_2pow20_g1_vs_libff_multi_exp(gpu, tmp_path):
     assert np.array_equal(got, want), "2^20-point G1 MSM differs from libff::multi_exp_with_mixed_addition on the same pairs"
 
 
+def libff_msm(tmp_path, curve, group, pts, sc, timeout=1400):
+    """the affine result words of libff's multi_exp_with_mixed_addition<BDLO12> over the same (base, scalar) pairs (oracle/_ref/ref_msm_bench)"""
+    ref = os.path.join(O.ROOT, "oracle", "_ref", "ref_msm_bench")
+    if not os.access(ref, os.X_OK):
+        pytest.fail("oracle/_ref/ref_msm_bench is missing: build it in the container (make -C oracle ref); it travels with the snapshot")
+    path = tmp_path / "pairs.bin"
+    with open(path, "wb") as f:
+        pts.tofile(f); sc.tofile(f)
+    r = subprocess.run([ref, str(path), str(len(sc)), ("MNT4753", "MNT6753")[curve], f"G{group}"], capture_output=True, text=True, timeout=timeout)
+    os.remove(path)
+    assert r.returncode == 0, r.stderr[-1000:]
+    hx = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["result_affine_hex"]
+    return np.array([int(hx[16 * i:16 * i + 16], 16) for i in range(len(hx) // 16)], dtype=np.uint64)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("curve,group,log_n", [(0, 2, 17), (1, 1, 15), (1, 2, 15)])
+def test_g2_and_mnt6753_at_size_vs_libff_multi_exp(gpu, tmp_path, curve, group, log_n):
+    """The other three MSMs of the prover DIRECTLY against libff (not through the test library's host arithmetic, not through a proof
+    hash): MNT4753 G2 at 2^17 (the irregular levels, the lane-split kernels and the window table at depth; the 2^20 form below is
+    opt-in for its host time), MNT6753 G1 and G2 at BASELINE's full 2^15.  Zero / one scalars and an identity base as a witness has them."""
+    n = 1 << log_n
+    pts = gpu.synth_points(curve, group, 142 + group, n)
+    sc = gpu.synth_scalars(curve, 145 + curve, n)
+    sc[0] = gpu.api.mont_one(curve); sc[1] = 0; sc[77] = 0; sc[n - 2] = gpu.api.mont_one(curve)
+    pts[n - 1] = 0
+    want = libff_msm(tmp_path, curve, group, pts, sc)
+    bs = gpu.BaseSet(curve, group, pts)
+    got = gpu.point_to_affine(curve, group, bs.msm(sc))
+    bs.close()
+    assert np.array_equal(got, want), f"MSM (curve {curve}, G{group}, 2^{log_n}) differs from libff::multi_exp_with_mixed_addition on the same pairs"
+
+
+@pytest.mark.timeout(3000)
+@pytest.mark.skipif(os.environ.get("MNT753_LIBFF_G2_FULL") != "1", reason="opt-in (MNT753_LIBFF_G2_FULL=1): libff's 2^20-point G2 MSM is ~2 min on 256 host threads")
+def test_full_size_2pow20_g2_vs_libff_multi_exp(gpu, tmp_path):
+    """BASELINE config[1]'s G2 MSM, all 2^20 pairs, against libff's own multi_exp_with_mixed_addition (B::multiexp_G2,
+    prover_reference_functions.cpp:257-265).  The round's run is recorded in profiles/."""
+    n = 1 << 20
+    pts = gpu.synth_points(0, 2, 242, n)
+    sc = gpu.synth_scalars(0, 245, n)
+    sc[0] = gpu.api.mont_one(0); sc[1] = 0; sc[n - 2] = gpu.api.mont_one(0)
+    pts[n - 1] = 0
+    want = libff_msm(tmp_path, 0, 2, pts, sc, timeout=2900)
+    bs = gpu.BaseSet(0, 2, pts)
+    got = gpu.point_to_affine(0, 2, bs.msm(sc))
+    bs.close()
+    assert np.array_equal(got, want)
+
+
 def test_large_g2_both_curves(gpu):
     for curve, n in ((0, 1 << 14), (1, 1 << 13)):
         pts = gpu.synth_points(curve, 2, 61, n); sc = gpu.synth_scalars(curve, 62, n)

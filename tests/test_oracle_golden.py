@@ -115,3 +115,24 @@ def test_reference_build_agrees_when_present(tmp_path):
     out = str(tmp_path / "ref.bin")
     subprocess.check_call([ref_main, "MNT6753", "compute", params, inp, out], stdout=subprocess.DEVNULL)
     assert filecmp.cmp(out, expected, shallow=False)
+
+
+@pytest.mark.parametrize("curve,group,n", [(0, 1, 256), (0, 2, 128), (1, 1, 256), (1, 2, 128)])
+def test_libff_msm_driver_on_the_golden_records(curve, group, n, tmp_path):
+    """oracle/_ref/ref_msm_bench (OUR driver around libff's multi_exp_with_mixed_addition<BDLO12>, the checker of the MSMs at size in
+    tests/test_msm_gpu.py and bench.py's cpu_baseline) for all four (curve, group) pairs: its file format and its result words against
+    the records the reference minted."""
+    ref = os.path.join(O.ROOT, "oracle", "_ref", "ref_msm_bench")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built on this machine")
+    import json
+    import subprocess
+    bases, scalars, result = G.msm(curve, group, n)
+    path = tmp_path / "pairs.bin"
+    with open(path, "wb") as f:
+        bases.tofile(f); scalars.tofile(f)
+    r = subprocess.run([ref, str(path), str(n), ("MNT4753", "MNT6753")[curve], f"G{group}"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1000:]
+    hx = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["result_affine_hex"]
+    got = np.array([int(hx[16 * i:16 * i + 16], 16) for i in range(len(hx) // 16)], dtype=np.uint64)
+    assert np.array_equal(got, result)
