@@ -123,6 +123,10 @@ def exchange_probe_main():
     res["backend"] = dist.get_backend()
     res["init_and_first_exchange_s"] = None
     res["librccl_mapped"] = any("librccl" in l for l in open("/proc/self/maps"))
+    try:
+        res["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())   # what the box's librccl reports
+    except Exception as e:   # noqa: BLE001 -- a label, never a reason to lose the measurement
+        res["rccl_version"] = f"unknown ({type(e).__name__})"
     res["setup_s"] = time.perf_counter() - t0
     dist.destroy_process_group()
     print(json.dumps(res), flush=True)
@@ -312,6 +316,12 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
         d = (1 << log2_d) - 1
         out.update(d=d, m=d + 1, synth_files_s=round(time.time() - t0, 2))
         files_ok = (sha256_file(pp) == expected["params_sha256"] and sha256_file(ip) == expected["input_sha256"]) if expected else None
+        # A prover that starts right behind another GPU process waits for the driver to take back the device memory that one returned
+        # (measured on one box: parameter load 3.84 s first, 7.0 s right behind another prover, 3.85 s after 20 s;
+        # profiles/r05/load_params_fresh_box.log) -- and this leg runs behind the bench's own profiled children: it starts after a pause
+        pause = 20.0 if log2_d >= 17 else 2.0
+        time.sleep(pause)
+        out["pause_before_s"] = pause
         t0 = time.time()
         # `repeat` proofs of the same input in ONE process: the first is the reference's metric (fresh process, parameters loaded,
         # then input -> output); the others show what a resident prover pays per proof
@@ -355,11 +365,8 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
         if gpus > 1:
             side.append(("fold_rccl", ["--repeat", "2", "--fold", "rccl"], {"MNT753_TRACE": "1"},
                          "partial points through mnt753_exchange_points (ncclAllGather over the prover's devices) in front of the serial fold"))
-        # A prover that starts right behind another one waits for the driver to take back the ~100 GB the first one returned: measured on
-        # one box, parameter load 3.84 s first, 7.0 s right behind it, 3.85 s after a pause of 20 s -- and without the warm-up MSM that
-        # wait lands INSIDE the first proof (0.90 s against 0.18 s; profiles/r05/load_params_fresh_box.log).  Neither is the prover's:
-        # the side children start after a pause.
-        pause = 20.0 if log2_d >= 17 else 2.0
+        # the side children start after the same pause (without the warm-up MSM the driver's reclaim can land INSIDE the first proof:
+        # 0.18 s on a settled device, 0.9-1.0 s behind another process; both are reported as measured)
         for key, flags, env_extra, note in side:
             for q in (op,):
                 if os.path.exists(q):

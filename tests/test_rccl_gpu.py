@@ -104,3 +104,44 @@ def test_exchange_points_through_the_c_abi(gpu):
         got, us = gpu.api.exchange_points([blk])
     assert len(got) == 1 and np.array_equal(got[0], blk) and 0 < us < 1e6
     print("mnt753_exchange_points, one device: %.1f us" % us)
+
+
+MULTI = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import ctypes as C
+import numpy as np
+from __graft_entry__ import load_package
+pkg = load_package()
+L = pkg.api.lib()
+n = %(n)d
+rc = L.mnt753_init_devices(n)
+assert rc == 0, L.mnt753_last_error().decode()
+assert L.mnt753_device_count() == n
+out = {}
+for words in (36, 432, 108):                      # the second call grows the buffers, the third fits what is there
+    blocks = [np.arange(words, dtype=np.uint64) * 1000003 + 17 * (g + 1) for g in range(n)]     # a different block per device
+    got, us = pkg.api.exchange_points(blocks)
+    assert len(got) == n
+    for g in range(n):
+        assert np.array_equal(got[g], blocks[g]), ("rank order", words, g)
+    out[str(words)] = us
+print(json.dumps(out), flush=True)
+'''
+
+
+def test_exchange_points_over_several_gpus_in_rank_order():
+    """The real N > 1 path of mnt753_exchange_points (ncclCommInitAll over the prover's devices, one ncclAllGather per device in a group
+    call, copy-back in rank order; the grow path between calls of different widths) on a box with at least two GPUs: a DIFFERENT block
+    per device, returned in rank order.  The test boxes of the build rounds have one GPU: skipped there (the advisor's request, for the
+    node the scaling runs use).  Child process: device setup is per process, and a communicator that hangs must not take pytest down."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs at least two GPUs in this process' view")
+    r = subprocess.run([sys.executable, "-c", MULTI % {"root": O.ROOT, "n": min(n, 8)}], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    us = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("mnt753_exchange_points over %d GPUs: %s us" % (min(n, 8), us))
