@@ -327,7 +327,8 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
         # then input -> output); the others show what a resident prover pays per proof
         # (every prover child under a timeout: a hang on hardware this builder never saw -- several real GPUs -- must cost one leg, not the run)
         try:
-            r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", str(repeat)] + dev_flags, capture_output=True, text=True, env=child_env, timeout=900)
+            r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", str(repeat)] + dev_flags, capture_output=True, text=True,
+                               env=dict(child_env, MNT753_TRACE=child_env.get("MNT753_TRACE", "1")), timeout=900)   # the trace: phases of the parameter load, on stderr
         except subprocess.TimeoutExpired:
             out.update(error="main_hip did not finish within 900 s", parity_ok=False)
             return out, cpu_out
@@ -339,6 +340,7 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
         m2 = re.search(r"load params: ([0-9.]+)s", r.stdout)
         sha = sha256_file(op)
         out["prover_stdout_first_proof"] = [l for l in r.stdout.strip().splitlines()][:9]
+        out["load_params_phases"] = [re.sub(r"\s+", " ", l.replace("mnt753: load params: ", "")) for l in r.stderr.splitlines() if l.startswith("mnt753: load params: ")]
         out.update(input_to_output_s=float(m1.group(1)) if m1 else None, load_params_s=float(m2.group(1)) if m2 else None,
                    wall_incl_params_s=round(wall, 3), sha256=sha,
                    timing_window="libsnark/main.cpp:203-270 (input load + compute + output write; parameters resident)",
