@@ -1,11 +1,15 @@
 // EXPERIMENT (round 5, NOT part of the library): the batched-affine pairing level at TWO waves per SIMD, for the levels whose operands
 // are the previous level's own blocked planes (everything but the first level) of a base field.  `git apply tools/experiments/pair2w/wiring.patch`
-// and a copy of this file into csrc/ put it behind MNT753_EXP_PAIR2W (1: k_pair_level2w, 2: k_pair_level1w at the end of the file).
+// and a copy of this file into csrc/ put it behind MNT753_EXP_PAIR2W (1: k_pair_level2w, 2: k_pair_level1w at the end of the file, 3: k_pair_level2w<.., PAIRED = false>).
 // Measured on MI355X, alternating with the shipped kernel on one box (profiles/r05/levels_two_waves_per_simd_pairs_on_one_simd.txt,
 // levels_no_image_register_prefetch.txt, sq_levels_*.txt), MNT4753 G1 2^20, per MSM:
 //     levels 2 + 3:        shipped 7.29-7.33 ms   two waves 7.20-7.25 ms (-1 %)   one wave, register prefetch 8.22 ms (+12 %)
 //     last irregular level: shipped 0.89-0.90 ms   two waves 0.92-0.93 ms (+3 %)   one wave, register prefetch 0.97-0.99 ms
 //     whole MSM:            23.94-24.23 ms         23.97-24.17 ms
+//     two INDEPENDENT waves per SIMD (PAIRED = false, MNT753_EXP_PAIR2W=3: a batch and an inversion per wave, twice the lanes):
+//                           levels 2 + 3 7.29-7.33 ms against 7.19-7.25 shipped on that box (+1 %), irregular levels +8 % / +24 %; the VALU is
+//                           saturated (0.53 active per wave-cycle, two waves) and the busy cycles fall 3 % while the time rises 1 %
+//                           (profiles/r05/levels_two_independent_waves_per_simd.txt, sq_levels_two_independent_waves.txt)
 // 10 % fewer VALU instructions and 0.93 of a SIMD's issue slots while its two waves are resident, and no gain: the SIMDs run at a lower
 // clock under it (the power bound of DESIGN.md 4.3), and the pair's rendezvous leaves SIMDs idle at the ends.  Not adopted.
 //
@@ -29,7 +33,9 @@
 
 namespace mnt753 {
 
-template <class C, bool last, bool IRR>
+// PAIRED = false: the two waves of a SIMD are independent -- a batch and an inversion each (twice the lanes of the one-wave kernel,
+// batches half as long): while one wave runs the 32-bit division steps of its inversion the other multiplies.
+template <class C, bool last, bool IRR, bool PAIRED = true>
 __global__ void __launch_bounds__(512, 1) k_pair_level2w(const uint4* __restrict__ src_planes, size_t src_stride, const uint32_t* __restrict__ offsG,
                                                         uint32_t n_buckets, uint32_t shift, uint32_t* __restrict__ out_sorted, uint4* __restrict__ out_planes,
                                                         size_t out_stride, uint4* __restrict__ prefix_ws, uint32_t min_B, uint32_t n_lanes,
@@ -43,11 +49,12 @@ __global__ void __launch_bounds__(512, 1) k_pair_level2w(const uint4* __restrict
   // so that every SIMD holds exactly one wave that inverts (with four-wave workgroups and pairs (0,1), (2,3) the two inverting waves of
   // the two workgroups of a CU met on SIMDs 0 and 2 and the inversion phase took twice as long: measured, 3 % slower than one wave).
   __shared__ __attribute__((aligned(16))) uint32_t xch[8 * 64 * FPS_WORDS];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, h = wave >> 2;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, h = PAIRED ? wave >> 2 : 0u;
+  constexpr uint32_t STEP = PAIRED ? 2u : 1u;
   const uint32_t S = offsG[n_buckets] << shift;
   const uint32_t B = max(min_B, (S + n_lanes - 1u) / n_lanes);
   const uint32_t NLe = S ? (S + B - 1u) / B : 1u;
-  const uint32_t t0w = (blockIdx.x * 4u + (wave & 3u)) * 64u;          // first batch of the wave pair
+  const uint32_t t0w = PAIRED ? (blockIdx.x * 4u + (wave & 3u)) * 64u : (blockIdx.x * 8u + wave) * 64u;   // first batch of the wave (pair)
   const bool wave_on = S != 0 && t0w < NLe;
   const uint32_t t = t0w + lane;
   const bool lane_on = wave_on && t < NLe;
@@ -83,7 +90,7 @@ __global__ void __launch_bounds__(512, 1) k_pair_level2w(const uint4* __restrict
   E run;
   F::one(run);
   // ---- forward: this wave's iterations, its own chain of prefix products
-  for (uint32_t it = h; it < n_it; it += 2u) {
+  for (uint32_t it = h; it < n_it; it += STEP) {
     const uint32_t o = it * NLe + t;
     const bool on = lane_on && o < S;
     const uint32_t oc = on ? o : (S - 1u);
@@ -114,7 +121,11 @@ __global__ void __launch_bounds__(512, 1) k_pair_level2w(const uint4* __restrict
   }
   // ---- the two chains of a batch meet: one inversion per pair of waves
   E inv;
-  {
+  if constexpr (!PAIRED) {
+    E tmp;
+    F::norm(tmp, run);
+    F::inv(inv, tmp);
+  } else {
     E tmp;
     F::norm(tmp, run);
     fp_store(my_x, tmp);
@@ -141,8 +152,8 @@ __global__ void __launch_bounds__(512, 1) k_pair_level2w(const uint4* __restrict
   }
   // ---- backward: individual inverses and the sums, this wave's iterations from the last one down
   if (n_it > h) {
-    const uint32_t it_last = h + ((n_it - 1u - h) & ~1u);
-    for (uint32_t it = it_last;; it -= 2u) {
+    const uint32_t it_last = PAIRED ? h + ((n_it - 1u - h) & ~1u) : n_it - 1u;
+    for (uint32_t it = it_last;; it -= STEP) {
       const uint32_t o = it * NLe + t;
       const bool on = lane_on && o < S;
       const uint32_t oc = on ? o : (S - 1u);
@@ -222,7 +233,7 @@ __global__ void __launch_bounds__(512, 1) k_pair_level2w(const uint4* __restrict
         fp_store_blk(px + 2 * out_stride, o >> 1, y1, 0u);
         if constexpr (last) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : ((o << 1) | ((out_flag & PF_NEG) ? 1u : 0u));
       }
-      if (it < 2u) break;
+      if (it < STEP) break;
     }
   }
 }
