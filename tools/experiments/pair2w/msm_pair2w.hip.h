@@ -10,6 +10,16 @@
 //                           levels 2 + 3 7.29-7.33 ms against 7.19-7.25 shipped on that box (+1 %), irregular levels +8 % / +24 %; the VALU is
 //                           saturated (0.53 active per wave-cycle, two waves) and the busy cycles fall 3 % while the time rises 1 %
 //                           (profiles/r05/levels_two_independent_waves_per_simd.txt, sq_levels_two_independent_waves.txt)
+//     one wave, register prefetch, REPAIRED (operands raw until their slot, unconditional loads: the first form waited for its loads
+//     where it issued them -- a flag taken out of a loaded quad, a load under a condition, each ends in `s_waitcnt` on the spot):
+//                           levels 2 + 3 7.57-7.61 ms against 7.37-7.42 shipped on that box (+2.7 %), first irregular level 1.41-1.42
+//                           against 1.52-1.53 (-7 %), last 0.89 against 0.91 (-2 %); 8.6 % fewer VALU instructions, VALU active 0.74,
+//                           waits 0.15.  What is left of the waits is the compiler's: with loads AND stores outstanding on gfx9's one
+//                           vmcnt it waits for everything (completion order between the two kinds is not defined), so the fourteen
+//                           stores of a slot are sat out at the top of the next whatever their place in the source (stores moved to
+//                           the top of the next slot, the form in this file: +6 % / -7 % / 0).  The shipped kernel's LDS-DMA image
+//                           with hand-placed waits is the answer to exactly that.
+//                           (profiles/r05/levels_no_image_register_prefetch_repaired.txt, ..._stores_at_top.txt)
 // 10 % fewer VALU instructions and 0.93 of a SIMD's issue slots while its two waves are resident, and no gain: the SIMDs run at a lower
 // clock under it (the power bound of DESIGN.md 4.3), and the pair's rendezvous leaves SIMDs idle at the ends.  Not adopted.
 //
@@ -289,32 +299,61 @@ __global__ void __launch_bounds__(256, 1) k_pair_level1w(const uint4* __restrict
     return on ? o : (S - 1u);
   };
 
+  // The prefetched operands stay RAW (seven quads per element, flag word included) until the slot that uses them: a flag taken out of
+  // the loaded quad where the load is issued makes the compiler wait for that load on the spot (first form of this kernel: s_waitcnt
+  // vmcnt(28) / (14) / (4) right behind the 35 loads -- the whole prefetch distance gone; VALU active 66 %).
+  struct Raw { uint4 q[7]; };
+  auto load_raw = [=](Raw& r, const uint4* p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.q[i] = p[(size_t)i * 64];
+  };
+  auto unpack = [=](E& e, const Raw& r) __attribute__((always_inline)) -> uint32_t {
+    uint32_t flag = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      e.l[4 * i] = r.q[i].x; e.l[4 * i + 1] = r.q[i].y; e.l[4 * i + 2] = r.q[i].z;
+      if (4 * i + 3 < NL) e.l[4 * i + 3] = r.q[i].w; else flag = r.q[i].w;
+    }
+    return flag;
+  };
   // ---- forward, the x coordinates of the next slot in flight
   E run;
   F::one(run);
   {
-    E x1, x2, x1n, x2n;
-    uint32_t f0, f1, ia, ib, leftover;
+    Raw r1, r2;
+    uint32_t ia, ib, leftover;
     bool on;
     uint32_t oc = slot_of(0u, on);
     in_index(oc, ia, ib, leftover);
-    f0 = load_q(x1, src_planes + ia);
-    f1 = load_q(x2, src_planes + ib);
-    if (leftover) f1 = PF_EMPTY;
+    load_raw(r1, src_planes + ia);
+    load_raw(r2, src_planes + ib);
+    // The stores of a slot are issued at the TOP of the next one, ahead of its loads: the compiler waits for EVERYTHING outstanding
+    // whenever loads and stores are pending together (one counter, completion order unknown between the two kinds), so a store issued
+    // at the end of a slot would be waited for at the top of the next -- its whole write latency, every slot.  At the top it has a
+    // slot's products to land in.
+    E st_run;
+    uint32_t st_o = 0, st_kind = 0;
+    bool st_on = false;
+    F::one(st_run);
     for (uint32_t it = 0; it < n_it; ++it) {
-      uint32_t f0n = 0, f1n = 0, ian = 0, ibn = 0, ocn = 0;
-      bool onn = false;
-      if (it + 1u < n_it) {
-        uint32_t lo;
-        ocn = slot_of(it + 1u, onn);
-        in_index(ocn, ian, ibn, lo);
-        f0n = load_q(x1n, src_planes + ian);
-        f1n = load_q(x2n, src_planes + ibn);
-        if (lo) f1n = PF_EMPTY;
+      E x1, x2;
+      uint32_t f0 = unpack(x1, r1);
+      uint32_t f1 = unpack(x2, r2);
+      if (leftover) f1 = PF_EMPTY;
+      if (st_on) fp_store_blk(prefix_ws, st_o, st_run, st_kind);
+      const uint32_t o = oc;
+      const bool on_c = on;
+      const uint32_t ia_c = ia, ib_c = ib;
+      {   // unconditional (the last iteration loads its own slot again): a load under a condition ends in register copies behind it
+        // -- and a wait for the loads they copy from, on the spot
+        oc = slot_of(min(it + 1u, n_it - 1u), on);
+        in_index(oc, ia, ib, leftover);
+        load_raw(r1, src_planes + ia);
+        load_raw(r2, src_planes + ib);
       }
       E den, tmp;
       uint32_t kind;
-      if (!on || (f0 & PF_EMPTY)) kind = PK_EMPTY;
+      if (!on_c || (f0 & PF_EMPTY)) kind = PK_EMPTY;
       else if (f1 & PF_EMPTY) kind = PK_SINGLE;
       else {
         kind = PK_ADD;
@@ -323,48 +362,62 @@ __global__ void __launch_bounds__(256, 1) k_pair_level1w(const uint4* __restrict
         if (same_x) { E du; F::sub(du, x2, x1); same_x = F::is_zero(du); }
         if (same_x) {
           E y1, y2;
-          (void)load_q(y1, src_planes + 2 * src_stride + ia);
-          (void)load_q(y2, src_planes + 2 * src_stride + ib);
+          (void)load_q(y1, src_planes + 2 * src_stride + ia_c);
+          (void)load_q(y2, src_planes + 2 * src_stride + ib_c);
           fp_addsub<M>(den, y1, y2, ((f0 ^ f1) & PF_NEG) != 0);
           if (F::is_zero(den)) { F::one(den); kind = PK_CANCEL; } else kind = PK_DBL;
         }
       }
-      if (on) fp_store_blk(prefix_ws, oc, run, kind);
+      st_run = run; st_o = o; st_kind = kind; st_on = on_c;
       if (kind <= PK_CANCEL) { F::mul_s(tmp, run, den); run = tmp; }
-      x1 = x1n; x2 = x2n; f0 = f0n; f1 = f1n; ia = ian; ib = ibn; oc = ocn; on = onn;
     }
+    if (st_on) fp_store_blk(prefix_ws, st_o, st_run, st_kind);
   }
   E inv;
   { E tmp; F::norm(tmp, run); F::inv(inv, tmp); }
   // ---- backward, all five operands of the next slot in flight
   {
-    E pre, x1, x2, y1, y2, pren, x1n, x2n, y1n, y2n;
-    uint32_t kflag, f0, f1, ia, ib, leftover;
+    Raw rp, r1, r2, ry1, ry2;
+    uint32_t ia, ib, leftover;
     bool on;
     uint32_t oc = slot_of(n_it - 1u, on);
     in_index(oc, ia, ib, leftover);
-    kflag = load_q(pre, prefix_ws + blk_index(oc));
-    f0 = load_q(x1, src_planes + ia);
-    f1 = load_q(x2, src_planes + ib);
-    (void)load_q(y1, src_planes + 2 * src_stride + ia);
-    (void)load_q(y2, src_planes + 2 * src_stride + ib);
-    if (leftover) f1 = PF_EMPTY;
+    load_raw(rp, prefix_ws + blk_index(oc));
+    load_raw(r1, src_planes + ia);
+    load_raw(r2, src_planes + ib);
+    load_raw(ry1, src_planes + 2 * src_stride + ia);
+    load_raw(ry2, src_planes + 2 * src_stride + ib);
+    E st_x, st_y;
+    uint32_t st_o = 0, st_flag = 0;
+    bool st_on = false;
+    F::one(st_x); st_y = st_x;
+    auto store_result = [=](uint32_t o, const E& x, const E& y, uint32_t flag) __attribute__((always_inline)) {
+      uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
+      fp_store_blk(px, o >> 1, x, flag);
+      fp_store_blk(px + 2 * out_stride, o >> 1, y, 0u);
+      if constexpr (last) out_sorted[o] = (flag & PF_EMPTY) ? ENTRY_EMPTY : ((o << 1) | ((flag & PF_NEG) ? 1u : 0u));
+    };
     for (uint32_t it = n_it - 1u;; --it) {
-      uint32_t kflagn = 0, f0n = 0, f1n = 0, ocn = 0;
-      bool onn = false;
-      if (it > 0u) {
-        uint32_t ian, ibn, lo;
-        ocn = slot_of(it - 1u, onn);
-        in_index(ocn, ian, ibn, lo);
-        kflagn = load_q(pren, prefix_ws + blk_index(ocn));
-        f0n = load_q(x1n, src_planes + ian);
-        f1n = load_q(x2n, src_planes + ibn);
-        (void)load_q(y1n, src_planes + 2 * src_stride + ian);
-        (void)load_q(y2n, src_planes + 2 * src_stride + ibn);
-        if (lo) f1n = PF_EMPTY;
-      }
+      E pre, x1, x2, y1, y2;
+      const uint32_t kflag = unpack(pre, rp);
+      uint32_t f0 = unpack(x1, r1);
+      uint32_t f1 = unpack(x2, r2);
+      (void)unpack(y1, ry1);
+      (void)unpack(y2, ry2);
+      if (leftover) f1 = PF_EMPTY;
+      if (st_on) store_result(st_o, st_x, st_y, st_flag);
       const uint32_t o = oc;
       const uint32_t kind = on ? kflag : (uint32_t)PK_EMPTY;
+      const bool on_c = on;
+      {
+        oc = slot_of(it > 0u ? it - 1u : 0u, on);
+        in_index(oc, ia, ib, leftover);
+        load_raw(rp, prefix_ws + blk_index(oc));
+        load_raw(r1, src_planes + ia);
+        load_raw(r2, src_planes + ib);
+        load_raw(ry1, src_planes + 2 * src_stride + ia);
+        load_raw(ry2, src_planes + 2 * src_stride + ib);
+      }
       const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
       uint32_t out_flag = PF_EMPTY;
       E den, num;
@@ -409,15 +462,10 @@ __global__ void __launch_bounds__(256, 1) k_pair_level1w(const uint4* __restrict
         }
         atomicAdd(&fix_count[lo], 1u);
       }
-      if (on) {
-        uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
-        fp_store_blk(px, o >> 1, x3, out_flag);
-        fp_store_blk(px + 2 * out_stride, o >> 1, y1, 0u);
-        if constexpr (last) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : ((o << 1) | ((out_flag & PF_NEG) ? 1u : 0u));
-      }
+      st_x = x3; st_y = y1; st_o = o; st_flag = out_flag; st_on = on_c;
       if (it == 0u) break;
-      pre = pren; x1 = x1n; x2 = x2n; y1 = y1n; y2 = y2n; kflag = kflagn; f0 = f0n; f1 = f1n; oc = ocn; on = onn;
     }
+    if (st_on) store_result(st_o, st_x, st_y, st_flag);
   }
 }
 
