@@ -10,7 +10,7 @@ LIB   := $(PKG)/libmnt753_hip.so
 # known-answer hooks.  Links against the product library; nothing of the product links against it.
 TESTLIB := $(PKG)/libmnt753_hip_test.so
 
-HIP_SRCS := mnt753_core.hip mnt753_msm.hip msm_sort.hip msm_inst_mnt4g1.hip msm_inst_mnt4g2.hip msm_inst_mnt6g1.hip msm_inst_mnt6g2.hip mnt753_fft.hip mnt753_synth.hip mnt753_r1cs.hip mnt753_exchange.hip
+HIP_SRCS := mnt753_core.hip mnt753_msm.hip msm_sort.hip msm_inst_mnt4g1.hip msm_inst_mnt4g2.hip msm_inst_mnt6g1.hip msm_inst_mnt6g2.hip mnt753_fft.hip mnt753_synth.hip mnt753_r1cs.hip mnt753_exchange.hip mnt753_selftest.hip
 HIP_OBJS := $(addprefix $(BUILD)/,$(HIP_SRCS:.hip=.o))
 TEST_SRCS := mnt753_testhooks.hip mnt753_synth_points.hip
 TEST_OBJS := $(addprefix $(BUILD)/,$(TEST_SRCS:.hip=.o))

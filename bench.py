@@ -47,8 +47,11 @@ sys.path.insert(0, ROOT)
 LOG_N = 20
 ALGO_BYTES_PER_PAIR = 288          # 192 B affine G1 base + 96 B scalar, read once
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
-MODMUL_PEAK_PER_S = 22.0e9         # measured chip peak of the 753-bit Montgomery multiplier (profiles/r01/mulbench_mi355x.txt)
-PROFILE_ROUND = "r05"
+MODMUL_PEAK_PER_S = 22.0e9         # MEASURED chip peak of the 753-bit Montgomery multiplier, VALU saturated, at the 1.96 GHz the chip sustains under it (profiles/r01/mulbench_mi355x.txt)
+# first principles beside it: 1024 SIMDs x 16 lanes per cycle (v_mad_u64_u32 is a full-rate instruction: 4 cycles per wave) x 2.4 GHz
+# nominal / 1458 multiply-adds per product -- a clock the chip does not hold under this load (power_and_clocks.txt: 2.07-2.10 GHz)
+MODMUL_PEAK_FIRST_PRINCIPLES_PER_S = 1024 * 16 * 2.4e9 / 1458
+PROFILE_ROUND = "r06"
 
 
 def sha256_file(path):
@@ -328,7 +331,7 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
         # (every prover child under a timeout: a hang on hardware this builder never saw -- several real GPUs -- must cost one leg, not the run)
         try:
             r = subprocess.run([exe, curve_name, "compute", pp, ip, op, "--repeat", str(repeat)] + dev_flags, capture_output=True, text=True,
-                               env=dict(child_env, MNT753_TRACE=child_env.get("MNT753_TRACE", "1")), timeout=900)   # the trace: phases of the parameter load, on stderr
+                               env=dict(child_env, MNT753_TRACE_LOAD="1"), timeout=900)   # phases of the parameter load on stderr; nothing is printed inside a proof's window (MNT753_TRACE would)
         except subprocess.TimeoutExpired:
             out.update(error="main_hip did not finish within 900 s", parity_ok=False)
             return out, cpu_out
@@ -364,8 +367,12 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
         if cold:
             side.append(("cold_process", ["--repeat", "2"], {"MNT753_NO_WARMUP": "1"},
                          "MNT753_NO_WARMUP=1: B::read_params builds the tables but runs nothing; the first proof pays first-touch page faults and code loading"))
+        if gpus == 1:
+            side.append(("one_shot", [], {"MNT753_TRACE_LOAD": "1"},
+                         "`main_hip <curve> compute <params> <input> <output>` as the reference's CLI is invoked (libsnark/main.cpp:274-293): one proof per "
+                         "process, so no window tables and no warm-up MSM (host/main.cpp); wall_incl_params_s is the clock around the whole process"))
         if gpus > 1:
-            side.append(("fold_rccl", ["--repeat", "2", "--fold", "rccl"], {"MNT753_TRACE": "1"},
+            side.append(("fold_rccl", ["--repeat", "2", "--fold", "rccl", "--peer-bench"], {"MNT753_TRACE": "1"},
                          "partial points through mnt753_exchange_points (ncclAllGather over the prover's devices) in front of the serial fold"))
         # the side children start after the same pause (without the warm-up MSM the driver's reclaim can land INSIDE the first proof:
         # 0.18 s on a settled device, 0.9-1.0 s behind another process; both are reported as measured)
@@ -387,12 +394,24 @@ def prove_leg(log2_d=20, curve_name="MNT4753", cpu=False, repeat=3, gpus=1, shar
             sha2 = sha256_file(op)
             out[key] = {"input_to_output_s": ts[0] if ts else None, "input_to_output_s_all": ts, "load_params_s": lp, "wall_incl_params_s": round(time.time() - t0, 3),
                         "same_bytes": sha2 == sha, "pause_before_s": pause, "note": note}
+            if key == "one_shot":
+                out["one_shot_wall_s"] = out[key]["wall_incl_params_s"]
+                out[key]["one_shot_policy_applied"] = "one-shot prover" in r2.stdout
+                out[key]["load_params_phases"] = [re.sub(r"\s+", " ", l.replace("mnt753: load params: ", "")) for l in r2.stderr.splitlines() if l.startswith("mnt753: load params: ")]
             if key == "fold_rccl":
                 out[key]["folded"] = "over RCCL" if "over RCCL" in r2.stderr else ("on the host (no communicator: " + ("logical devices share a GPU" if share else "librccl unavailable") + ")")
                 # what the box granted for the device pairs the sharded prover copies between (one MNT753_TRACE line per ordered pair)
                 pairs = [l for l in r2.stderr.splitlines() if l.startswith("mnt753: device ") and " reads device " in l]
                 out["peer_access"] = {"ordered_pairs": len(pairs), "direct": sum("direct" in l for l in pairs), "staged_through_host": sum("staged" in l for l in pairs),
                                       "same_gpu": sum("same GPU" in l for l in pairs)}
+                # the copies DESIGN.md section 5 assumes at 2.0 ms per 100 MB, measured by the child on this box (main_hip --peer-bench)
+                copies = re.findall(r"peer copy 100 MB device (\d+) -> (\d+): ([0-9.]+) ms \(([0-9.]+) GB/s\), (.*)", r2.stdout)
+                if copies:
+                    out["peer_copy_100MB"] = [{"src": int(a), "dst": int(b), "ms": float(ms), "GB_per_s": float(gb), "path": how.strip()} for a, b, ms, gb, how in copies]
+                    to0 = [c["ms"] for c in out["peer_copy_100MB"] if c["dst"] == 0]
+                    out["peer_copy_100MB_to_device0_ms"] = max(to0) if to0 else None
+                    out["peer_copy_note"] = ("measured on this box; values on logical devices that share one GPU are local copies, not xGMI" if share else
+                                             "measured on this box: what DESIGN.md section 5 assumed at 2.0 ms")
                 lat = [float(m) for m in re.findall(r"devices in ([0-9.]+) us", r2.stderr)]
                 if lat:
                     out[key]["all_gather_us"] = {"first": lat[0], "min": min(lat), "calls": len(lat)}
@@ -486,19 +505,29 @@ def main():
     if want_prove and world == 1:
         legs = prove_legs() if args.prove_log2_d is None else {"prove": prove_leg(d4, "MNT4753")[0], "prove_mnt6753": prove_leg(d6, "MNT6753")[0], "cpu_prove": []}
     elif want_prove:
-        gate = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bench_prove_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.done")
+        # one gate per launch: the launcher's pid, its rendezvous port and (torchrun) its run id name it, so that a stale file of an
+        # earlier launch cannot let ranks through; rank 0 writes its outcome into it and the others leave at once when it failed
+        gate = os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                            f"bench_prove_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}.done")
         if rank == 0:
+            status = "failed"
             try:
+                if os.path.exists(gate):
+                    os.remove(gate)
                 legs = prove_legs(world, share, d4, d6)
+                status = "ok"
             finally:
-                with open(gate, "w") as f:
-                    f.write("done\n")
+                with open(gate + ".tmp", "w") as f:
+                    f.write(status + "\n")
+                os.replace(gate + ".tmp", gate)
         else:
             t_wait = time.time()
             while not os.path.exists(gate):
                 if time.time() - t_wait > 3600:
                     raise SystemExit("bench.py: rank 0's prove legs did not finish within an hour")
                 time.sleep(0.2)
+            if open(gate).read().strip() != "ok":
+                raise SystemExit("bench.py: rank 0's prove legs failed; this rank leaves before it touches a GPU")
     exchange = None
     if world == 1 and not args.no_exchange and args.log_n == LOG_N and not under_profiler:
         exchange = exchange_leg()
@@ -662,7 +691,7 @@ def main():
                        "window_table": plan["window_table"],
                        "limbs": "27 x 28-bit limbs in u32 registers, 64-bit multiply-add columns (v_mad_u64_u32 / v_mad_i64_i32); exact integer arithmetic",
                        "parallelism": f"slice-per-gpu x{world}, all_gather (RCCL) of one projective point per rank, serial fold (multiexp.tcc:417-440)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "roofline": {"bound": "int-mad (hbm fraction reported per contract)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_info": traffic_info, "kernel": kernel_name, "kernel_ms": acc,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PAIR * n_local,
                          "note": "bucket accumulation phase of one MSM (HIP events on the launch stream). `achieved` is ALGORITHMIC bytes / time as the "
@@ -671,6 +700,10 @@ def main():
                          "pair_levels": regular_levels, "irregular_levels": irr_levels, "products_per_entry": prod_per_entry,
                          "modmul_per_s": prod_per_entry * windows * n_local / (acc * 1e-3), "modmul_peak_per_s": MODMUL_PEAK_PER_S,
                          "modmul_frac": prod_per_entry * windows * n_local / (acc * 1e-3) / MODMUL_PEAK_PER_S,
+                         "modmul_peak_first_principles_per_s": MODMUL_PEAK_FIRST_PRINCIPLES_PER_S,
+                         "modmul_frac_of_first_principles": prod_per_entry * windows * n_local / (acc * 1e-3) / MODMUL_PEAK_FIRST_PRINCIPLES_PER_S,
+                         "modmul_peak_note": "modmul_peak_per_s is MEASURED (multiplier microbenchmark, 1.96 GHz sustained); the first-principles figure is 1024 SIMDs x 16 "
+                                             "lanes x 2.4 GHz / 1458 multiply-adds -- at a nominal clock the chip does not hold under integer multiply-add load",
                          "mixed_addition_equivalents_per_s": windows * n_local / (acc * 1e-3)},
             "phases_ms": {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},
             "precompute_ms": precompute_ms,
@@ -750,7 +783,7 @@ def main():
             # passes over HBM: 604 MB moved for 201 MB algorithmic; (m / 2) log2 m = 10.5 M butterflies, one product each but for the
             # first stage, whose only twiddle is 1 (skipped since round 4): 19 products per pair of elements.
             fft_s = extras["fft_2p20_ms"] * 1e-3
-            line["roofline_fft"] = {"bound": "hbm", "achieved": 192.0 * m / fft_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            line["roofline_fft"] = {"bound": "int-mad in its LDS passes (hbm fraction reported per contract)", "achieved": 192.0 * m / fft_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": 192.0 * m / fft_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                                     "kernel": "k_ntt_group x3 (one 2^20 FFT over Fr of MNT4753; HIP events on the launch stream)", "kernel_ms": extras["fft_2p20_ms"],
                                     "algorithmic_bytes_per_launch": 192 * m, "passes_over_hbm": 3, "moved_bytes_by_design": 3 * 192 * m,

@@ -42,6 +42,7 @@ extern "C" {
 #define MNT753_EHIP (-3)     /* a HIP runtime call failed */
 #define MNT753_ENOMEM (-4)   /* device or host allocation failed */
 #define MNT753_EDOMAIN (-5)  /* FFT size is not a supported power of two for this field */
+#define MNT753_ESELFTEST (-6) /* mnt753_self_test: a known-answer check failed -- this build must not be used to prove */
 
 /* FFT kinds: libfqfft basic_radix2_domain::{FFT,iFFT,cosetFFT,icosetFFT}
  * (depends/libfqfft/libfqfft/evaluation_domain/domains/basic_radix2_domain.tcc:62-96);
@@ -64,6 +65,17 @@ int mnt753_init(int device);
  * (mnt753_copy_peer_async, xGMI); one projective point back per device, folded on the host in rank order with mnt753_point_add.
  * MNT753_SHARE_DEVICE=1 (development) maps the logical devices onto however many are visible. */
 int mnt753_init_devices(int n_devices);
+/* Known-answer self-test of THIS build on the current device: expected words computed by the reference's own code (libff's
+ * multi_exp_with_mixed_addition, libfqfft's compute_H call sequence, libff's group classes) are embedded in the library as constants
+ * (csrc/mnt753_selftest_data.h, minted by tools/gen_selftest_data.py through oracle/_ref -- data, none of the oracle's code).
+ * level 0: the host tails (point decoding, addition, doubling, affine output) on one libff record per group; level 1: plus a 256-point
+ * MSM per (curve, group) -- with and without the batched-affine levels of the large sets in front of it -- and compute_H on a 2^8
+ * domain per curve (~20 ms); level 2: plus the same MSMs over a window table (~0.1 s).  0 if everything agrees, MNT753_ESELFTEST (and
+ * a message naming the check) if one word differs, another code if a call failed.  Why: a proof is only as sound as the build that
+ * computed it, and the compiler has miscompiled kernels of this library before; the reference carries a check of the same
+ * purpose around its prover (libsnark/main.cpp:295-343).  B::init_public_params runs level 1 once per process (MNT753_SELFTEST=0
+ * skips it, MNT753_SELFTEST=2 raises it); `main_hip <curve> self-test` runs level 2. */
+int mnt753_self_test(int level);
 int mnt753_device_count(void);
 int mnt753_set_device(int logical_device);
 int mnt753_get_device(void);   /* the calling thread's current logical device (0 before mnt753_set_device) */
@@ -146,6 +158,13 @@ int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective);
  * latest start AT THE TIME b starts; it is dropped (no wait) if `first` is freed before b's next start. */
 int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first);
 
+/* Window tables of the base sets created FROM NOW ON: mode 1 (default) -- a set of 4096 points or more gets the table of its window
+ * multiples 2^(cw) P_i at creation (0.33 s of kernels per 2^20 G1 points, 1.3 s for 2^20 G2 points; an MSM over it then takes
+ * 23.7 ms instead of 38-43); mode 0 -- no tables: what a process that will prove ONCE wants, because the reference's CLI is such a
+ * process (libsnark/main.cpp:196-203 loads the parameters per invocation, :274-293) and a table never pays for itself in one proof.
+ * The wrapper's B::one_shot / main_hip's default for a single job use it.  MNT753_MSM_PRECOMP=0 / 1 in the environment overrides
+ * both.  Returns the previous mode. */
+int mnt753_msm_set_window_table(int mode);
 /* window size override (0 = automatic); returns previous value.  Tuning knob, not part of the reference. */
 int mnt753_msm_set_window_bits(int c);
 /* time of the last mnt753_msm call's kernels in milliseconds (HIP events on the launch stream):

@@ -114,6 +114,12 @@ public:
   // Where the partial points of a sharded multiexp meet: false (default) -- on the host, where mnt753_msm_finish leaves them anyway;
   // true -- through an RCCL all-gather over the devices (mnt753_exchange_points, xGMI) before the fold.  Also MNT753_FOLD=rccl.
   static void fold_over_rccl(bool on);
+  // true: this process proves ONCE -- what the reference's `./main <curve> compute ...` is (libsnark/main.cpp:196-203 loads the
+  // parameters per invocation, :274-293).  read_params then builds the base sets without their window tables and runs no warm-up MSM:
+  // a table costs 0.33 s per 2^20 G1 points (1.3 s for the G2 set) and saves 20 ms per MSM, which pays from the second proof of a
+  // resident prover (--repeat / --serve / several jobs), never in one.  Same proof bytes.  main_hip sets it for a single job on one
+  // device; MNT753_ONE_SHOT=0 / 1 and MNT753_MSM_PRECOMP=0 / 1 override.  Call before read_params.
+  static void one_shot(bool on);
   // The step before the hot path: instead of reading ca / cb / cc from the input file (where the
   // reference's generator put them, generate_parameters.cpp:44-57), evaluate the constraint system on the assignment on the
   // device -- the first loop of r1cs_to_qap_witness_map (reductions/r1cs_to_qap/r1cs_to_qap.tcc:223-237).

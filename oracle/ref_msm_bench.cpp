@@ -12,6 +12,11 @@
 // (tests/test_msm_gpu.py).  A G2 base is x then y, each extension-degree base-field elements (serialization.hpp:94-113).
 //
 //   ref_msm_bench <file> <n> [MNT4753|MNT6753 [G1|G2]]
+//
+// Fourth argument H instead of a group (round 6): the file holds ca[m], cb[m], cc[m] (Fr, wire format) and the program runs compute_H
+// exactly as libsnark/main.cpp:104-163 spells it with libfqfft calls, printing coefficients_for_H (m + 1 elements) as hex -- how
+// tools/gen_selftest_data.py mints the expected words of the product's self-test (mnt753_self_test) for ITS inputs.
+//   ref_msm_bench <file> <m> MNT4753|MNT6753 H
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +28,7 @@
 #include <libff/algebra/curves/mnt753/mnt6753/mnt6753_pp.hpp>
 #include <libff/algebra/scalar_multiplication/multiexp.hpp>
 #include <libsnark/serialization.hpp>
+#include <libfqfft/evaluation_domain/get_evaluation_domain.hpp>
 
 using namespace libff;
 
@@ -56,15 +62,43 @@ template <class ppT, class G, G (*read_point)(FILE*)> int run(FILE* f, size_t n)
   return 0;
 }
 
+template <class ppT> int run_h(FILE* f, size_t m) {
+  std::vector<Fr<ppT>> ca(m), cb(m), cc(m);
+  for (auto* v : {&ca, &cb, &cc}) for (size_t i = 0; i < m; ++i) (*v)[i] = read_fr<ppT>(f);
+  fclose(f);
+  libff::inhibit_profiling_info = true;
+  auto domain = libfqfft::get_evaluation_domain<Fr<ppT>>(m);
+  const Fr<ppT> g = Fr<ppT>::multiplicative_generator;
+  domain->iFFT(ca); domain->iFFT(cb);
+  domain->cosetFFT(ca, g); domain->cosetFFT(cb, g);
+  for (size_t i = 0; i < m; ++i) ca[i] = ca[i] * cb[i];
+  domain->iFFT(cc); domain->cosetFFT(cc, g);
+  for (size_t i = 0; i < m; ++i) ca[i] = ca[i] - cc[i];
+  domain->divide_by_Z_on_coset(ca);
+  domain->icosetFFT(ca, g);
+  printf("{\"m\": %zu, \"result_hex\": \"", m);
+  for (size_t i = 0; i < m; ++i) hex_fq(ca[i].mont_repr.data);
+  const Fr<ppT> z = Fr<ppT>::zero();
+  hex_fq(z.mont_repr.data);
+  printf("\"}\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: %s <bases+scalars file> <n> [MNT4753|MNT6753 [G1|G2]]\n", argv[0]); return 2; }
   const size_t n = strtoull(argv[2], nullptr, 10);
   const bool mnt6 = argc > 3 && !strcmp(argv[3], "MNT6753");
   const bool g2 = argc > 4 && !strcmp(argv[4], "G2");
+  const bool h = argc > 4 && !strcmp(argv[4], "H");
   if (argc > 3 && !mnt6 && strcmp(argv[3], "MNT4753")) { fprintf(stderr, "curve: MNT4753 or MNT6753\n"); return 2; }
-  if (argc > 4 && !g2 && strcmp(argv[4], "G1")) { fprintf(stderr, "group: G1 or G2\n"); return 2; }
+  if (argc > 4 && !g2 && !h && strcmp(argv[4], "G1")) { fprintf(stderr, "group: G1 or G2 (or H: compute_H)\n"); return 2; }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 1; }
+  if (h) {
+    if (mnt6) { mnt6753_pp::init_public_params(); return run_h<mnt6753_pp>(f, n); }
+    mnt4753_pp::init_public_params();
+    return run_h<mnt4753_pp>(f, n);
+  }
   if (mnt6) {
     mnt6753_pp::init_public_params();
     return g2 ? run<mnt6753_pp, G2<mnt6753_pp>, read_g2<mnt6753_pp>>(f, n) : run<mnt6753_pp, G1<mnt6753_pp>, read_g1<mnt6753_pp>>(f, n);

@@ -64,6 +64,8 @@ def lib():
         "mnt753_msm_start": (i, [vp, sz, vp, i, sz, vp]),
         "mnt753_msm_finish": (i, [vp, u64p]),
         "mnt753_msm_set_window_bits": (i, [i]),
+        "mnt753_msm_set_window_table": (i, [i]),
+        "mnt753_self_test": (i, [i]),
         "mnt753_msm_order_after": (i, [vp, vp]),
         "mnt753_msm_last_timing": (i, [C.POINTER(C.c_float)]),
         "mnt753_msm_last_plan": (i, [C.POINTER(C.c_int)]),
@@ -145,6 +147,11 @@ def _u64(a):
 
 def init(device=0):
     _check(lib().mnt753_init(int(device)), "mnt753_init")
+
+
+def self_test(level=1):
+    """mnt753_self_test: the known answers embedded in the library (include/mnt753_hip.h); raises Mnt753Error on a mismatch"""
+    _check(lib().mnt753_self_test(level), "mnt753_self_test")
 
 
 def exchange_points(blocks):

@@ -34,6 +34,8 @@ struct FieldFp {
   static constexpr bool HAS_LAZY = true;
   static HD void mul_s(E& r, const E& a, const E& b) { fp_mul_s(r, a, b); }
   static HD void sqr_s(E& r, const E& a) { fp_sqr_s(r, a); }
+  static HD void mul_s_ip(E& b, E& a) { fp_mul_s_ip(b, a); }         // b <- a b in place, operands opaque in place (fp753.hip.h)
+  static HD void sqr_s_keep(E& r, E& a) { fp_sqr_s_keep(r, a); }
   static HD void sub_raw(E& r, const E& a, const E& b) { fp_sub_raw(r, a, b); }
   static HD void addsub_raw(E& r, const E& a, const E& y, bool subtract) { fp_addsub_raw(r, a, y, subtract); }
   static HD void norm(E& r, const E& a) { fp_norm(r, a); }

@@ -347,6 +347,93 @@ HD void fp_sqr_s(Fp<M>& r, const Fp<M>& a_in) {
   }
   r.l[NL - 1] = (uint32_t)acc;
 }
+// ---- the same two products for a step loop that keeps its operands where the multiplier reads them (round 6) -------------------
+// fp_mul_s / fp_sqr_s take copies of their operands (fp_opaque_limb returns a NEW value: where the operand stays live the compiler
+// has to copy it first) and hand back a fresh result that the caller then moves to wherever the next product wants it: in the step
+// loop of k_pair_level that routing was ~80 register moves per product (msm_kernels.hip.h).  Here the operands pass through the empty
+// asm IN PLACE (the variable itself is the opaque value from then on, no copy), and the product overwrites b: limb j of the result is
+// produced in column 27 + j, which reads a_i, b_i only for i > j, so r_j can take the register of b_j.  (Whether it DOES is the register
+// allocator's decision: pinning the destinations with tied asm operands -- "v_and_b32 %0, 0xfffffff, %1" : "=v"(r) : "v"(x), "0"(b_j) --
+// made it copy b_j to a fresh register first, one more move per limb instead of one fewer; measured with tools/isa_walk.py, not kept.)
+template <int M>
+HD void fp_opaque_inplace(Fp<M>& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i < NL; ++i) asm("" : "+v"(a.l[i]));
+#else
+  (void)a;
+#endif
+}
+// b <- a * b * 2^-756 (signed limbs, as fp_mul_s); a keeps its value
+template <int M>
+HD void fp_mul_s_ip(Fp<M>& b, Fp<M>& a) {
+  int64_t acc = 0;
+  uint64_t acc2 = 0;
+  uint32_t m[NL];
+  fp_opaque_inplace(a);
+  fp_opaque_inplace(b);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += (int64_t)acc2;
+    acc2 = 0;
+    m[k] = ((uint32_t)acc * FPC[M].inv) & LMASK;
+    acc += (int64_t)((uint64_t)m[k] * FPC[M].p[0]);
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[k - i];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += (int64_t)acc2;
+    acc2 = 0;
+    b.l[k - NL] = (uint32_t)acc & LMASK;      // b_j is dead behind column 26 + j
+    acc >>= LB;
+  }
+  b.l[NL - 1] = (uint32_t)acc;
+}
+// r <- a * a * 2^-756 (signed limbs, |a_i| < 2^29, as fp_sqr_s); a keeps its value
+template <int M>
+HD void fp_sqr_s_keep(Fp<M>& r, Fp<M>& a) {
+  int64_t acc = 0;
+  uint64_t acc2 = 0;
+  uint32_t m[NL];
+  int32_t d[NL];
+  fp_opaque_inplace(a);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) d[i] = fp_opaque_limb(a.l[i] << 1);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; ++i) acc += (int64_t)(int32_t)a.l[i] * d[k - i];
+    if ((k & 1) == 0) acc += (int64_t)(int32_t)a.l[k / 2] * (int32_t)a.l[k / 2];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += (int64_t)acc2;
+    acc2 = 0;
+    m[k] = ((uint32_t)acc * FPC[M].inv) & LMASK;
+    acc += (int64_t)((uint64_t)m[k] * FPC[M].p[0]);
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; 2 * i < k; ++i) acc += (int64_t)(int32_t)a.l[i] * d[k - i];
+    if ((k & 1) == 0) acc += (int64_t)(int32_t)a.l[k / 2] * (int32_t)a.l[k / 2];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc2 += (uint64_t)m[i] * FPC[M].p[k - i];
+    acc += (int64_t)acc2;
+    acc2 = 0;
+    r.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+}
 // limb-wise a - b and a +- b (the sign chosen per lane): no carries, signed limbs
 template <int M>
 HD void fp_sub_raw(Fp<M>& r, const Fp<M>& a, const Fp<M>& b) {

@@ -139,11 +139,14 @@ struct HFp {
   // u = x, v = p, x1 u' = x1' x, ... ends with u or v = 1 after at most 2 * 753 halvings; ~20 us instead of Fermat's 0.3 ms -- the
   // three affine results of a proof are normalised on the host, which was 6 % of an MNT6753 prove.  The stored word is a R (Montgomery
   // form), its integer inverse is a^-1 R^-1: two products with R^2 give a^-1 R.  0 -> 0 like the Fermat form.  Not constant time
-  // (the prover's outputs are public).
+  // (the prover's outputs are public).  from_words() is a raw copy of caller / device words: a non-canonical stored word (l >= p) is
+  // reduced first -- l = p or a multiple of it would otherwise pass is_zero(), drive u to 0 and never leave the halving loop -- and the
+  // main loop is bounded (each round halves u or v at least once: 2 * 768 rounds at most) with the Fermat form behind it.
   HFp inverse() const {
-    if (is_zero()) return zero();
     uint64_t u[12], v[12], x1[12], x2[12];
     memcpy(u, l, sizeof(u)); memcpy(v, FPC[M].p64, sizeof(v));
+    for (int k = 0; k < 40000 && geq_p(u); ++k) sub_p(u);           // R / p < 2^15.2: canonical after at most ~37 055 subtractions (one for any word a kernel wrote)
+    { uint64_t o = 0; for (int i = 0; i < 12; ++i) o |= u[i]; if (o == 0) return zero(); }
     memset(x1, 0, sizeof(x1)); x1[0] = 1; memset(x2, 0, sizeof(x2));
     auto is_one = [](const uint64_t* a) { uint64_t o = a[0] ^ 1u; for (int i = 1; i < 12; ++i) o |= a[i]; return o == 0; };
     auto shr1 = [](uint64_t* a) { for (int i = 0; i < 11; ++i) a[i] = (a[i] >> 1) | (a[i + 1] << 63); a[11] >>= 1; };
@@ -152,7 +155,9 @@ struct HFp {
     auto geq = [](const uint64_t* a, const uint64_t* b) { for (int i = 11; i >= 0; --i) if (a[i] != b[i]) return a[i] > b[i]; return true; };
     auto sub = [](uint64_t* a, const uint64_t* b) { u128 bw = 0; for (int i = 0; i < 12; ++i) { u128 d = (u128)a[i] - b[i] - bw; a[i] = (uint64_t)d; bw = (d >> 64) & 1; } return (bool)bw; };
     auto sub_mod = [&](uint64_t* a, const uint64_t* b) { if (sub(a, b)) add_p(a); };
+    int rounds = 0;
     while (!is_one(u) && !is_one(v)) {
+      if (++rounds > 2 * 768 + 2) return inverse_fermat();          // cannot happen for u in [1, p), p prime; never loop on a surprise
       while (!(u[0] & 1u)) { shr1(u); halve_mod(x1); }
       while (!(v[0] & 1u)) { shr1(v); halve_mod(x2); }
       if (geq(u, v)) { sub(u, v); sub_mod(x1, x2); } else { sub(v, u); sub_mod(x2, x1); }

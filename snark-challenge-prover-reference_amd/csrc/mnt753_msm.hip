@@ -11,6 +11,8 @@
 
 namespace mnt753 {
 int g_window_bits_override = 0;
+int g_force_pair_levels = -1, g_force_irr_levels = -1;
+int g_window_table_mode = 1;   // mnt753_msm_set_window_table: 1 = tables for base sets of 4096 points and more, 0 = none
 float g_last_timing[5] = {0, 0, 0, 0, 0};
 int g_last_plan[4] = {0, 0, 0, 0};
 int g_last_pair_levels = 0;
@@ -140,6 +142,12 @@ int mnt753_msm_finish(mnt753_bases* b, uint64_t* out_projective) {
   if (b->curve == MNT753_CURVE_MNT4753)
     return b->group == MNT753_G1 ? msm_finish_mnt4g1(b, out_projective) : msm_finish_mnt4g2(b, out_projective);
   return b->group == MNT753_G1 ? msm_finish_mnt6g1(b, out_projective) : msm_finish_mnt6g2(b, out_projective);
+}
+
+int mnt753_msm_set_window_table(int mode) {
+  const int old = g_window_table_mode;
+  g_window_table_mode = mode != 0 ? 1 : 0;
+  return old;
 }
 
 int mnt753_msm_set_window_bits(int c) {

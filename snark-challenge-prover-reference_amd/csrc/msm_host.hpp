@@ -22,6 +22,8 @@ using namespace mnt753;
 
 namespace mnt753 {
 extern int g_window_bits_override;
+extern int g_window_table_mode;
+extern int g_force_pair_levels, g_force_irr_levels;   // >= 0: mnt753_self_test puts the level kernels onto its small sets (as MNT753_MSM_PAIR / _IRR do for the tests)
 extern float g_last_timing[5];
 extern int g_last_plan[4];
 extern int g_last_pair_levels;
@@ -212,8 +214,10 @@ template <class C> int ensure_pair_ws_for(mnt753_bases* b, const MsmPlan& p, siz
 template <class C>
 int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_t n) {
   const size_t wire_bytes = n * 2 * wire_coord_words<C>() * 4;
-  // window table: on by default for base sets large enough to amortise it (MNT753_MSM_PRECOMP=0 turns it off)
-  bool want_table = n >= 4096;
+  // window table: on by default for base sets large enough to amortise it over the proofs of a resident prover; a one-proof process
+  // turns it off for the sets it creates (mnt753_msm_set_window_table(0): a table costs 0.33 s per 2^20 G1 points to build and saves
+  // 20 ms per MSM); MNT753_MSM_PRECOMP=0 / 1 overrides both
+  bool want_table = (n >= 4096 && g_window_table_mode != 0) || (n > 0 && g_window_table_mode == 2);   // 2: mnt753_self_test, level 2
   if (const char* e = getenv("MNT753_MSM_PRECOMP")) want_table = atoi(e) != 0 && n > 0;
   int pc = 0, pW = 1;
   if (want_table) {
@@ -326,6 +330,7 @@ template <class V>
 int pair_levels(uint64_t entries) {
   if constexpr (V::F::DEG != 1 && V::F::LANES == 1) return 0;   // (one-lane Fq2 / Fq3: not instantiated by the product)
   else {
+    if (g_force_pair_levels >= 0) return g_force_pair_levels;
     if (const char* e = getenv("MNT753_MSM_PAIR")) { int v = atoi(e); return v < 0 ? 0 : (v > 6 ? 6 : v); }
     if constexpr (V::F::LANES == 1) {          // G1: 2^18 points and up (2^17: 5.3 ms plain, 5.5 with two levels)
       if (entries >= ((uint64_t)1 << 23)) return 3;
@@ -348,6 +353,7 @@ int pair_levels(uint64_t entries) {
 //   2^20 points:  G1 25.7 -> 25.2 ms with two levels, Fq2 G2 70.0 -> 66.5 ms with three;  3 * 2^20 G1 points (H | L | B1): 66.3 -> 62.8.
 template <class C>
 int irr_levels_for(uint64_t entries, int regular_levels, uint32_t n_buckets) {
+  if (g_force_irr_levels >= 0) return g_force_irr_levels;
   if (const char* e = getenv("MNT753_MSM_IRR")) { int v = atoi(e); return v < 0 ? 0 : (v > 8 ? 8 : v); }
   const double lanes = (double)std::min<uint32_t>(machine_lanes(C::F::LANES), C::F::LANES == 3 ? PAIR_MAX_LANES / 3u : PAIR_MAX_LANES / (uint32_t)C::F::LANES);
   const double min_batch = C::F::LANES == 1 ? 16.0 : 10.0;

@@ -589,6 +589,15 @@ constexpr uint32_t ENTRY_EMPTY = 0xffffffffu;
 #else
 #define PAIR_ROW(r) (r)
 #endif
+#ifndef MNT753_PAIR_WAVES
+#define MNT753_PAIR_WAVES 1
+#endif
+#ifndef MNT753_PAIR_DIET_SPLIT
+#define MNT753_PAIR_DIET_SPLIT 1
+#endif
+#ifndef MNT753_PAIR_DIET
+#define MNT753_PAIR_DIET 1
+#endif
 enum : uint32_t { PK_ADD = 0, PK_DBL = 1, PK_CANCEL = 2, PK_SINGLE = 3, PK_EMPTY = 4 };
 
 // b + (negate ? -y : y) without a separate negation: the subtrahend / addend is chosen limb-wise
@@ -663,7 +672,13 @@ constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
 // (profiles/r05/level1_whole_row_pieces.txt) -- the number of DMA instructions is what the wave pays for, not their address arithmetic.)
 // portions the LDS-DMA of the next slot's image is issued in, one ahead of each of the first products of a slot: gathered rows of a
 // base field in four, of the lane-split fields in five, own planes in three (profiles/r03/ab_first_level_dma_portions.txt)
-constexpr uint32_t PAIR_DMA_STEPS_FIRST = 4, PAIR_DMA_STEPS_LATER = 3;
+#ifndef MNT753_PAIR_DMA_LATER
+#define MNT753_PAIR_DMA_LATER 3
+#endif
+#ifndef MNT753_PAIR_PRE_TOP
+#define MNT753_PAIR_PRE_TOP 1      // development: 1 = the prefix product read with the other operands, 0 = where it is multiplied, 2 = 1 for the first level only
+#endif
+constexpr uint32_t PAIR_DMA_STEPS_FIRST = 4, PAIR_DMA_STEPS_LATER = MNT753_PAIR_DMA_LATER;
 
 #ifdef MNT753_PAIR_TIMING
 // development: cycle totals of k_pair_level per wave (s_memtime): [0] forward, [1] inversion, [2] backward, [3] waves, [4..] ad hoc
@@ -783,7 +798,7 @@ static __global__ void __launch_bounds__(IRR_BLOCK) k_irr_fill(const uint32_t* _
 // last:  besides the four planes at out_planes (stride out_stride) the level writes the entry list out_sorted (slot o -> row o
 //        of the planes as (o << 1) | sign) that the accumulate kernel (BLOCKED instantiation) reads.
 template <class C, bool first, bool last, bool IRR = false>
-__global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restrict__ src_rows,
+__global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uint32_t* __restrict__ src_rows,
                                                       const uint32_t* __restrict__ entries, const uint4* __restrict__ src_planes,
                                                       size_t src_stride, const uint32_t* __restrict__ offsG, uint32_t n_buckets,
                                                       uint32_t shift, uint32_t* __restrict__ out_rows, uint32_t* __restrict__ out_sorted,
@@ -811,6 +826,10 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
   // base fields: differences limb-wise without carries, signed-product multiplier, two normalisations per addition instead of
   // seven carry-propagating subtractions (fp753.hip.h, "lazy arithmetic")
   constexpr bool LAZY = has_lazy<F>::value;
+  // round 6: the backward sweep keeps its operands where the multiplier reads them (below, "operands in place")
+  constexpr bool DIET = LAZY && MNT753_PAIR_DIET;
+  // ... and the same loop shape for the lane-split fields (their fused multiplier, eager additions): MNT753_PAIR_DIET_SPLIT
+  constexpr bool DIET_S = !LAZY && F::LANES > 1 && MNT753_PAIR_DIET_SPLIT;
   extern __shared__ uint4 pair_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint4* img = pair_lds + (size_t)wave * PAIR_LDS_WAVE_QUADS;
@@ -1063,7 +1082,10 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     if constexpr (IRR) { if (it >= 2u) sw_nn = irr_word(it - 2u); }
     read_rows(n & 1u, std::false_type{}, img, f0, f1, x1, y1, x2, y2);
     if constexpr (IRR) { if (sw_cur >> 31) f1 = PF_EMPTY; }
-    const uint32_t kflag = fp_from_lds(pre, pre_img + lane, 64u);
+    uint32_t kflag;
+    constexpr bool PRE_TOP = !DIET || MNT753_PAIR_PRE_TOP == 1 || (MNT753_PAIR_PRE_TOP == 2 && first);
+    if constexpr (PRE_TOP) kflag = fp_from_lds(pre, pre_img + lane, 64u);
+    else kflag = pre_img[6u * 64u + lane].w;
     const uint32_t kind = on ? kflag : (uint32_t)PK_EMPTY;
     const bool more = n + 1u < n_it;
     // blocked index (uint4 units) of the next slot's element: the per-lane part of the addresses of its planes and prefix product
@@ -1074,32 +1096,34 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
     if constexpr (first) { if (more) issue_entries(it >= 2u ? it - 2u : 0u, n & 1u); }
     const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
     uint32_t out_flag = PF_EMPTY;
-    E num, ysave;
-    ysave = y1;
-    if (kind == PK_ADD) {
-      out_flag = f1 & PF_NEG;
-      if constexpr (LAZY) {
-        F::sub_raw(den, x2, x1);
-        F::addsub_raw(num, y2, y1, !flip);
+    E num, ysave, yo;
+    if constexpr (!DIET && !DIET_S) {
+      ysave = y1;
+      if (kind == PK_ADD) {
+        out_flag = f1 & PF_NEG;
+        if constexpr (LAZY) {
+          F::sub_raw(den, x2, x1);
+          F::addsub_raw(num, y2, y1, !flip);
+        } else {
+          F::sub(den, x2, x1);
+          fp_addsub<M>(num, y2, y1, !flip);         // y2 - y1  or  y2 + y1
+        }
+      } else if (kind == PK_DBL) {
+        // P1 == P2 as signed points, s1 y1 = s2 y2: lambda = (3 x^2 + a) / (2 s1 y1) = s1 lambda' with the denominator 2 y1 formed
+        // exactly as in the forward sweep (y1 + y2, or y1 - y2 when the flags differ); result (x3, s1 (lambda' (x1 - x3) - y1))
+        E a;
+        fp_addsub<M>(den, y1, y2, flip);
+        F::mul(tmp, x1, x1);
+        F::add(num, tmp, tmp); F::add(num, num, tmp);
+        C::coeff_a(a);
+        F::add(num, num, a);
+        out_flag = f0 & PF_NEG;
       } else {
-        F::sub(den, x2, x1);
-        fp_addsub<M>(num, y2, y1, !flip);         // y2 - y1  or  y2 + y1
+        // cancellation, odd leftover, empty slot: denominator 1 -- the lane runs the same products and its inversion chain
+        // keeps its value (inv * 1)
+        F::one(den);
+        num = den;
       }
-    } else if (kind == PK_DBL) {
-      // P1 == P2 as signed points, s1 y1 = s2 y2: lambda = (3 x^2 + a) / (2 s1 y1) = s1 lambda' with the denominator 2 y1 formed
-      // exactly as in the forward sweep (y1 + y2, or y1 - y2 when the flags differ); result (x3, s1 (lambda' (x1 - x3) - y1))
-      E a;
-      fp_addsub<M>(den, y1, y2, flip);
-      F::mul(tmp, x1, x1);
-      F::add(num, tmp, tmp); F::add(num, num, tmp);
-      C::coeff_a(a);
-      F::add(num, num, a);
-      out_flag = f0 & PF_NEG;
-    } else {
-      // cancellation, odd leftover, empty slot: denominator 1 -- the lane runs the same products and its inversion chain
-      // keeps its value (inv * 1)
-      F::one(den);
-      num = den;
     }
     // The five products of a slot run through ONE inlined multiplier (and one squarer) in a wave-uniform step loop; every
     // result replaces an operand that is dead by then, which keeps the loop's live state at seven elements:
@@ -1117,9 +1141,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       // 68.5 / 68.5 with four; profiles/r03/ab_first_level_dma_portions.txt)
       constexpr uint32_t DMA_STEPS = first ? (LN == 1 ? PAIR_DMA_STEPS_FIRST : 5u) : PAIR_DMA_STEPS_LATER;
       constexpr uint32_t PER_STEP = (BWD_PIECES + DMA_STEPS - 1u) / DMA_STEPS;
-#pragma nounroll
-      for (int step = 0; step < 5; ++step) {
-        PAIR_T(tdm0);
+      auto dma_step = [=](int step) __attribute__((always_inline)) {
         if (more && (uint32_t)step < DMA_STEPS) {
           // portion `step` of the next slot's image.  The pieces are named by constants (so that plane / quad offsets are scalar
           // constants), and the per-lane part of every address passes through an opaque move:
@@ -1173,60 +1195,166 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
             default: portion(std::integral_constant<uint32_t, 4>{}, vb_next); break;
           }
         }
-#ifdef MNT753_PAIR_TIMING
-        tw_c += __builtin_readcyclecounter() - tdm0;
-#endif
-        switch (step) {
-          case 0: opa = inv; opb = pre; break;
-          case 1: opa = inv; opb = den; break;
-          case 2: opa = num; opb = pre; break;
-          case 3: opa = den; opb = den; break;
-          default: opa = den; opb = num; break;
-        }
-        if constexpr (LAZY) {
-          if (step == 3) F::sqr_s(res, opa); else F::mul_s(res, opa, opb);
-        } else if constexpr (has_sqr<F>::value) {
-          if (step == 3) F::sqr(res, opa); else F::mul(res, opa, opb);
+      };
+      if constexpr (DIET) {
+        // Operands in place (round 6).  The loop above routed two operands into the multiplier and one result out of it per product
+        // (~80 register moves each, and the nine live elements spilled into AGPRs and back).  Here the multiplier works on two
+        // blocks A, B with B <- A * B (fp_mul_s_ip), and every value is PRODUCED where its product reads it:
+        //   0: A = inv, B = den = x2 - x1       B <- inv * den, kept as the next slot's inv (the one copy of the slot)
+        //   1: B = pre (out of the LDS image)   B <- inv * pre = 1 / den
+        //   2: A = num = y2 -+ y1               B <- num / den = lambda
+        //   3: S = B^2 (the squarer keeps B)    x2 <- norm(S - x1 - x2) = x3,  A = x1 - x3
+        //   4:                                   B <- lambda * (x1 - x3),  yo <- norm(B -+ y1) = y3'
+        // The prefix product leaves its image behind step 1, before the portion of the DMA that overwrites it (the last one).
+        static_assert((PRE_TOP || ROW_PIECES >= 2u * PER_STEP) && DMA_STEPS <= 4u, "a prefix product read at step 1 must not have its pieces in portions 0, 1; the loop has four iterations");
+        E A = inv, B;
+        if (kind == PK_ADD) {
+          out_flag = f1 & PF_NEG;
+          F::sub_raw(B, x2, x1);
+        } else if (kind == PK_DBL) {
+          // P1 == P2 as signed points, s1 y1 = s2 y2: lambda = (3 x^2 + a) / (2 s1 y1) = s1 lambda' with the denominator 2 y1 formed
+          // exactly as in the forward sweep; result (x3, s1 (lambda' (x1 - x3) - y1)).  The numerator is handed to step 2 INSIDE y2
+          // (y2 is dead for this lane): y2 <- N +- y1 limb-wise, so that the y2 -+ y1 of step 2 gives back the limbs of N
+          E a, t, nn;
+          fp_addsub<M>(B, y1, y2, flip);
+          F::mul(t, x1, x1);
+          F::add(nn, t, t); F::add(nn, nn, t);
+          C::coeff_a(a);
+          F::add(nn, nn, a);
+          F::addsub_raw(y2, nn, y1, flip);
+          out_flag = f0 & PF_NEG;
         } else {
-          F::mul(res, opa, opb);
+          F::one(B);                              // cancellation, odd leftover, empty slot: the chain keeps its value
         }
-        switch (step) {
-          case 0: pre = res; break;
-          case 1: inv = res; break;
-          case 2: den = res; break;
-          case 3:
-            if constexpr (LAZY) {
-              // x3 = lambda^2 - x1 - x2 limb-wise, ONE normalisation; x1 - x3 stays raw (it only feeds the last product)
-              F::sub_raw(res, res, x1);
-              F::sub_raw(res, res, x2);
-              F::norm(x2, res);
-              F::sub_raw(num, x1, x2);
-            } else {
-              F::sub(res, res, x1);
-              F::sub(x2, res, x2);
-              F::sub(num, x1, x2);
-            }
-            break;
-          default:
-            if constexpr (LAZY) {
-              F::addsub_raw(res, res, y1, !(kind == PK_ADD && flip));
-              F::norm(y1, res);
-            } else {
-              fp_addsub<M>(y1, res, y1, !(kind == PK_ADD && flip));
-            }
-            break;
+        // ONE merge point per iteration: what a product leaves to do is done in front of the next one (the squaring, which has its own
+        // instance, sits in the last iteration's preparation), the multiplier is the last thing in the body, and the loop's back edge
+        // follows it directly -- with a second switch behind the multiplier the compiler copied both operand blocks twice per product.
+#pragma nounroll
+        for (int step = 0; step < 4; ++step) {
+          dma_step(step);
+          switch (step) {
+            case 0: break;
+            case 1:
+              inv = B;
+              if constexpr (PRE_TOP) B = pre; else (void)fp_from_lds(B, pre_img + lane, 64u);
+              break;
+            case 2: F::addsub_raw(A, y2, y1, !flip); break;    // y2 - y1  or  y2 + y1
+            default:
+              F::sqr_s_keep(A, B);
+              F::sub_raw(A, A, x1);
+              F::sub_raw(A, A, x2);
+              F::norm(x2, A);
+              F::sub_raw(A, x1, x2);
+              break;
+          }
+          F::mul_s_ip(B, A);
         }
+        F::addsub_raw(B, B, y1, !(kind == PK_ADD && flip));
+        F::norm(B, B);
+        yo = B;
+      } else if constexpr (DIET_S) {
+        // the lane-split fields in the same loop shape: B <- A * B through their fused multiplier (F::mul: one fp_mul2 / fp_mul3 per
+        // lane, partners' operands by ds_bpermute), eager additions, five DMA portions in the first level (the fifth between the
+        // squaring and the last product)
+        E A = inv, B, t;
+        if (kind == PK_ADD) {
+          out_flag = f1 & PF_NEG;
+          F::sub(B, x2, x1);
+        } else if (kind == PK_DBL) {
+          E a, nn;
+          fp_addsub<M>(B, y1, y2, flip);
+          F::mul(t, x1, x1);
+          F::add(nn, t, t); F::add(nn, nn, t);
+          C::coeff_a(a);
+          F::add(nn, nn, a);
+          fp_addsub<M>(y2, nn, y1, flip);         // y2 <- N +- y1, so that the y2 -+ y1 of step 2 is N again (mod p)
+          out_flag = f0 & PF_NEG;
+        } else {
+          F::one(B);
+        }
+        // ONE multiplier instance (2187 / 2916 multiply-adds: a second one would put the loop past the instruction cache): the squaring
+        // goes through it too, lambda parked around it
+        E lam;
+#pragma nounroll
+        for (int step = 0; step < 5; ++step) {
+          dma_step(step);
+          switch (step) {
+            case 0: break;
+            case 1: inv = B; B = pre; break;
+            case 2: fp_addsub<M>(A, y2, y1, !flip); break;
+            case 3: lam = B; A = B; break;
+            default:
+              F::sub(t, B, x1);
+              F::sub(x2, t, x2);
+              F::sub(A, x1, x2);
+              B = lam;
+              break;
+          }
+          F::mul(t, A, B);
+          B = t;
+        }
+        fp_addsub<M>(yo, B, y1, !(kind == PK_ADD && flip));
+      } else {
+#pragma nounroll
+        for (int step = 0; step < 5; ++step) {
+          PAIR_T(tdm0);
+          dma_step(step);
+#ifdef MNT753_PAIR_TIMING
+          tw_c += __builtin_readcyclecounter() - tdm0;
+#endif
+          switch (step) {
+            case 0: opa = inv; opb = pre; break;
+            case 1: opa = inv; opb = den; break;
+            case 2: opa = num; opb = pre; break;
+            case 3: opa = den; opb = den; break;
+            default: opa = den; opb = num; break;
+          }
+          if constexpr (LAZY) {
+            if (step == 3) F::sqr_s(res, opa); else F::mul_s(res, opa, opb);
+          } else if constexpr (has_sqr<F>::value) {
+            if (step == 3) F::sqr(res, opa); else F::mul(res, opa, opb);
+          } else {
+            F::mul(res, opa, opb);
+          }
+          switch (step) {
+            case 0: pre = res; break;
+            case 1: inv = res; break;
+            case 2: den = res; break;
+            case 3:
+              if constexpr (LAZY) {
+                // x3 = lambda^2 - x1 - x2 limb-wise, ONE normalisation; x1 - x3 stays raw (it only feeds the last product)
+                F::sub_raw(res, res, x1);
+                F::sub_raw(res, res, x2);
+                F::norm(x2, res);
+                F::sub_raw(num, x1, x2);
+              } else {
+                F::sub(res, res, x1);
+                F::sub(x2, res, x2);
+                F::sub(num, x1, x2);
+              }
+              break;
+            default:
+              if constexpr (LAZY) {
+                F::addsub_raw(res, res, y1, !(kind == PK_ADD && flip));
+                F::norm(y1, res);
+              } else {
+                fp_addsub<M>(y1, res, y1, !(kind == PK_ADD && flip));
+              }
+              break;
+          }
+        }
+        yo = y1;
       }
     }
     if (kind == PK_SINGLE) {                    // odd leftover: copy, the sign travels in the flag
       out_flag = f0 & PF_NEG;
       x2 = x1;
-      y1 = ysave;
+      if constexpr (DIET || DIET_S) yo = y1; else yo = ysave;
     }
     {
       if (kind == PK_CANCEL) {                  // P + (-P): emit D, remember to take it out of the bucket again
         fp_load(x2, gen + cw);
-        fp_load(y1, gen + EW + cw);
+        fp_load(yo, gen + EW + cw);
         out_flag = 0;
         if (comp == 0) {
           const uint32_t f = o >> shift;        // final slot -> bucket: largest b with offsG[b] <= f
@@ -1249,7 +1377,7 @@ __global__ void __launch_bounds__(256, 1) k_pair_level(const uint32_t* __restric
       const uint32_t j = (o >> 1) * LN + comp;
       uint4* px = out_planes + (size_t)(o & 1u) * out_stride;
       fp_store_blk(px, j, x2, out_flag);
-      fp_store_blk(px + 2 * out_stride, j, y1, 0u);
+      fp_store_blk(px + 2 * out_stride, j, yo, 0u);
       if constexpr (last) {   // the entry list of the accumulate kernel: slot o is row o of the planes
         if (comp == 0) out_sorted[o] = (out_flag & PF_EMPTY) ? ENTRY_EMPTY : ((o << 1) | ((out_flag & PF_NEG) ? 1u : 0u));
       }

@@ -37,10 +37,13 @@ static bool g_touch_all = false;   // --touch-all (with --ref-order): read Bt1, 
 static bool g_fused_c = true;   // C = Ht + Lt + r Bt1 as one MSM over H | L | B1 (B::groth16_C); --unfused-c / --ref-order: the reference's five multiexps
 static int g_gpus = 0;   // --gpus N: parameter vectors sharded over N devices of this node (0: MNT753_GPUS or 1)
 static bool g_serve = false;    // --serve: after the listed jobs, read further "<input> <output>" lines from stdin until EOF
+static int g_one_shot = -1;     // -1: decided from the job list (one job, no --serve, one device: a one-proof process); --one-shot / --tables force it
+static bool g_peer_bench = false;   // --peer-bench (with --gpus N): time the peer copies the sharded prover makes, 100 MB each, before proving
 static int g_fold_rccl = -1;    // --fold rccl | host: where the partial points of a sharded multiexp meet (default: MNT753_FOLD, else host)
 
 typedef std::chrono::steady_clock clk;
 static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+static void ck(int rc, const char* what) { if (rc) throw std::runtime_error(std::string(what) + ": " + mnt753_last_error()); }
 
 // cuda_prover_piecewise.cu:18-53.  Overwrites ca (and cb, cc), like the reference.
 template <typename B>
@@ -162,13 +165,59 @@ void prove_one(typename B::groth16_params* params, const char* input_path, const
   B::delete_groth16_input(input);
 }
 
+// --peer-bench: what DESIGN.md section 5 ASSUMES (2.0 ms for 100 MB over one xGMI link), measured on the box the prover runs on: the
+// copies of the sharded prove -- the transformed cb / cc 1 -> 0 and 2 -> 0 (cuda_prover_piecewise.cu:24-34 keeps them on one device;
+// here they cross), a slice of coefficients_for_H 0 -> g -- as one 100 MB mnt753_copy_peer_async each, best of three, with what the
+// platform granted for the pair.  One line per copy on stdout; bench.py --gpus N carries them.
+static void peer_bench() {
+  const int n = mnt753_device_count();
+  if (n < 2) { printf("peer copy: one device, nothing to measure\n"); return; }
+  const size_t bytes = (size_t)100 << 20;
+  std::vector<void*> buf(n, nullptr);
+  for (int g = 0; g < n; ++g) { ck(mnt753_set_device(g), "mnt753_set_device"); ck(mnt753_dev_alloc(&buf[g], bytes), "mnt753_dev_alloc"); ck(mnt753_dev_memset(buf[g], g, bytes), "mnt753_dev_memset"); }
+  std::vector<std::pair<int, int>> pairs;   // (source, destination)
+  pairs.emplace_back(1, 0);
+  if (n > 2) pairs.emplace_back(2, 0);
+  for (int g = 1; g < n; ++g) pairs.emplace_back(0, g);
+  static const char* const names[] = {"same GPU (logical devices share it)", "direct (peer access)", "staged through host memory"};
+  for (auto pr : pairs) {
+    int how = MNT753_PEER_STAGED;
+    ck(mnt753_enable_peer_access(pr.second, pr.first, &how), "mnt753_enable_peer_access");
+    double best = 1e30;
+    for (int k = 0; k < 4; ++k) {     // the first pass warms the path
+      ck(mnt753_set_device(pr.first), "mnt753_set_device"); ck(mnt753_sync(nullptr), "mnt753_sync");
+      ck(mnt753_set_device(pr.second), "mnt753_set_device"); ck(mnt753_sync(nullptr), "mnt753_sync");
+      const auto t0 = clk::now();
+      ck(mnt753_copy_peer_async(pr.second, buf[pr.second], pr.first, buf[pr.first], bytes), "mnt753_copy_peer_async");
+      ck(mnt753_set_device(pr.second), "mnt753_set_device"); ck(mnt753_sync(nullptr), "mnt753_sync");
+      const double ms = 1e3 * secs(t0, clk::now());
+      if (k > 0 && ms < best) best = ms;
+    }
+    printf("peer copy 100 MB device %d -> %d: %.3f ms (%.1f GB/s), %s\n", pr.first, pr.second, best, bytes / best / 1e6, names[how >= 0 && how <= 2 ? how : 2]);
+  }
+  for (int g = 0; g < n; ++g) { ck(mnt753_set_device(g), "mnt753_set_device"); ck(mnt753_dev_free(buf[g]), "mnt753_dev_free"); }
+  ck(mnt753_set_device(0), "mnt753_set_device");
+}
+
 // jobs: (input, output) pairs; all proved against the same resident parameters
 template <typename B>
 void run_prover(const char* params_path, const std::vector<std::pair<std::string, std::string>>& jobs, const char* r1cs_path = nullptr) {
   if (g_gpus > 0) B::use_devices(g_gpus);
   B::fuse_C(g_fused_c);
   if (g_fold_rccl >= 0) B::fold_over_rccl(g_fold_rccl != 0);
+  // The reference's CLI is a one-shot process: parameters loaded per invocation, one proof, exit (libsnark/main.cpp:196-203, :274-293).
+  // Invoked the same way -- one job, no --repeat / --serve, one device -- this prover builds no window tables and runs no warm-up MSM:
+  // 2.7 s of table kernels and 0.7 s of warm-up would buy 0.1 s on the one proof.  A resident prover (several jobs, --repeat, --serve)
+  // and a sharded one (--gpus) keep them.  --tables / --one-shot force either; MNT753_MSM_PRECOMP stays the override underneath.
+  {
+    const char* eg = getenv("MNT753_GPUS");
+    const bool several_devices = g_gpus > 1 || (g_gpus == 0 && eg && atoi(eg) > 1);
+    const bool one = g_one_shot >= 0 ? g_one_shot != 0 : (jobs.size() == 1 && !g_serve && !several_devices);
+    B::one_shot(one);
+    if (!g_quiet && one) printf("one-shot prover: no window tables (one job, no --repeat / --serve; --tables builds them)\n");
+  }
   B::init_public_params();
+  if (g_peer_bench) peer_bench();
   auto t0 = clk::now();
   auto params = B::read_params(params_path);
   typename B::r1cs* cs = r1cs_path ? B::read_r1cs(r1cs_path) : nullptr;
@@ -217,7 +266,6 @@ static void slurp(const char* path, long offset_from_end, void* dst, size_t byte
   if (fread(dst, 1, bytes, f) != bytes) { fclose(f); throw std::runtime_error(std::string("short read: ") + path); }
   fclose(f);
 }
-static void ck(int rc, const char* what) { if (rc) throw std::runtime_error(std::string(what) + ": " + mnt753_last_error()); }
 static int complete_proof(int curve, const char* keys_path, const char* input_path, const char* challenge_path, const char* out_path,
                           const char* s_file, uint64_t s_seed) {
   const size_t g1 = 24, g2 = mnt753_affine_words(curve, MNT753_G2);
@@ -270,8 +318,16 @@ int main(int argc, char** argv) {
     try { return complete_proof(curve, argv[3], argv[4], argv[5], argv[6], s_file, s_seed); }
     catch (const std::exception& e) { fprintf(stderr, "main_hip: %s\n", e.what()); return 1; }
   }
+  if (argc >= 3 && !strcmp(argv[2], "self-test")) {
+    // `main_hip <curve> self-test`: the known-answer checks of this build at their widest (level 2: also over window tables)
+    if (mnt753_init(0) != 0) { fprintf(stderr, "main_hip: %s\n", mnt753_last_error()); return 1; }
+    const int rc = mnt753_self_test(2);
+    if (rc != 0) { fprintf(stderr, "main_hip: %s\n", mnt753_last_error()); return 1; }
+    printf("self-test: all known answers of the reference agree (level 2)\n");
+    return 0;
+  }
   if (argc < 6) {
-    fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--gpus N] [--unfused-h] [--ref-order] [--quiet]\n"
+    fprintf(stderr, "usage: %s MNT4753|MNT6753 compute <params> <input> <output> [<input2> <output2> ...] [--repeat N] [--serve] [--gpus N] [--tables | --one-shot] [--unfused-h] [--unfused-c] [--ref-order] [--fold rccl|host] [--quiet]\n"
                     "  further (input, output) pairs and --repeat prove against the parameters that are already resident on the GPU\n", argv[0]);
     return 2;
   }
@@ -298,6 +354,14 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--c-last")) g_c_first = false;
     else if (!strcmp(argv[i], "--touch-all")) g_touch_all = true;
     else if (!strcmp(argv[i], "--fused-c")) g_fused_c = true;
+    else if (!strcmp(argv[i], "--peer-bench")) g_peer_bench = true;
+    else if (!strcmp(argv[i], "--tables")) g_one_shot = 0;      // build the window tables even for a single proof
+    else if (!strcmp(argv[i], "--one-shot")) g_one_shot = 1;    // no window tables, no warm-up MSM, whatever the job list
+    else {
+      // an option this prover does not have (or one that lost its argument), or an input without its output: refuse, do not guess
+      fprintf(stderr, argv[i][0] == '-' ? "main_hip: unknown option %s\n" : "main_hip: input %s without an output path\n", argv[i]);
+      return 2;
+    }
   }
   std::string curve(argv[1]), mode(argv[2]);
   try {

@@ -28,12 +28,14 @@ namespace mnt753_hip_detail {
 }
 static void check(int rc, const char* what) { if (rc != 0) fail(what); }
 static bool trace_on() { const char* e = getenv("MNT753_TRACE"); return e && atoi(e) != 0; }
-// MNT753_TRACE=1: where the seconds of a parameter load go (file reads, base sets with their window tables, domains, warm-up)
+// MNT753_TRACE=1 or MNT753_TRACE_LOAD=1: where the seconds of a parameter load go (file reads, base sets with their window tables,
+// domains, warm-up).  MNT753_TRACE_LOAD alone prints nothing inside a proof's timing window (bench.py's timed child uses it).
+static bool trace_load_on() { const char* e = getenv("MNT753_TRACE_LOAD"); return trace_on() || (e && atoi(e) != 0); }
 struct LoadTrace {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void lap(const char* what) {
     const auto t1 = std::chrono::steady_clock::now();
-    if (trace_on()) fprintf(stderr, "mnt753: load params: %-46s %7.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    if (trace_load_on()) fprintf(stderr, "mnt753: load params: %-46s %7.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
     t0 = t1;
   }
 };
@@ -126,6 +128,13 @@ static int g_fused_c = -1;
 static bool fused_c() {
   if (g_fused_c < 0) { const char* e = getenv("MNT753_FUSED_C"); g_fused_c = e ? (atoi(e) != 0) : 1; }
   return g_fused_c != 0;
+}
+// B::one_shot(true): the process will prove once (the reference's CLI, libsnark/main.cpp:274-293): read_params builds no window tables
+// and runs no warm-up MSM -- both pay only over the proofs of a resident prover.  MNT753_ONE_SHOT=0 / 1 overrides.
+static int g_one_shot = 0;
+static bool one_shot_mode() {
+  if (const char* e = getenv("MNT753_ONE_SHOT")) return atoi(e) != 0;
+  return g_one_shot != 0;
 }
 // contiguous slice g of n elements over n_dev devices (multiexp.tcc:417-431: one = n / chunks, the last slice takes the remainder)
 static void slice_bounds(size_t n, int n_dev, int g, size_t* lo, size_t* hi) {
@@ -633,6 +642,21 @@ template <int CURVE> void HIP_B::init_public_params() {
         if (trace) fprintf(stderr, "mnt753: device %d reads device %d: %s\n", a, b, names[how >= 0 && how <= 2 ? how : 2]);
       }
   } else check(mnt753_init(0), "mnt753_init");
+  // Known answers of THIS build, once per process, before anything is proved with it (mnt753_self_test, include/mnt753_hip.h; the
+  // reference's check of the same purpose: libsnark/main.cpp:295-343).  ~20 ms inside the parameter-load phase, outside the timing
+  // window (main.cpp:201-203).  A mismatch is fatal: a prover must not write proofs with arithmetic that fails its known answers.
+  static bool self_tested = false;
+  if (!self_tested) {
+    int level = 1;
+    if (const char* e = getenv("MNT753_SELFTEST")) level = atoi(e);
+    if (level > 0) {
+      const auto t0 = std::chrono::steady_clock::now();
+      check(mnt753_self_test(level > 2 ? 2 : level), "mnt753_self_test");
+      if (trace_load_on()) fprintf(stderr, "mnt753: load params: %-46s %7.3f s\n", "known-answer self-test of this build",
+                                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    self_tested = true;
+  }
 }
 
 template <int CURVE> void HIP_B::print_G1(G1* a) {
@@ -1044,6 +1068,7 @@ template <int CURVE> typename HIP_B::G1* HIP_B::groth16_C(groth16_params* p, vec
 }
 template <int CURVE> void HIP_B::fuse_C(bool on) { g_fused_c = on ? 1 : 0; }
 template <int CURVE> void HIP_B::fold_over_rccl(bool on) { g_fold_rccl = on ? 1 : 0; }
+template <int CURVE> void HIP_B::one_shot(bool on) { g_one_shot = on ? 1 : 0; }
 
 template <int CURVE> typename HIP_B::groth16_input* HIP_B::read_input(const char* path, groth16_params* params) {
   return new groth16_input(path, params->d, params->m);
@@ -1070,6 +1095,7 @@ template <int CURVE> typename HIP_B::field* HIP_B::input_r(groth16_input* in) {
 // prover), the later ones always at 0.22 s.  MNT753_NO_WARMUP=1 turns it off.
 template <int CURVE> static void warm_up(typename mnt753_hip_impl<CURVE>::groth16_params* p) {
   if (const char* e = getenv("MNT753_NO_WARMUP")) { if (atoi(e) != 0) return; }
+  if (one_shot_mode()) return;    // one proof: what the warm-up would pay at load time the proof pays itself, once
   std::vector<ShardedBases*> sets;
   for (auto* sb : {p->B2.get(), p->HLB.get(), p->A.get(), p->B1.get(), p->L.get(), p->H.get()}) if (sb) sets.push_back(sb);
   size_t n = 1;
@@ -1086,6 +1112,12 @@ template <int CURVE> static void warm_up(typename mnt753_hip_impl<CURVE>::groth1
     for (auto& set : pm->sets) check(mnt753_msm_finish(set->h, sink), "mnt753_msm_finish(warm-up)");
 }
 template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const char* path) {
+  // a one-proof process builds its base sets without window tables (include/mnt753_hip.h, mnt753_msm_set_window_table)
+  struct TableMode {
+    int old;
+    explicit TableMode(bool none) : old(mnt753_msm_set_window_table(none ? 0 : 1)) { if (trace_load_on() && none) fprintf(stderr, "mnt753: one-shot prover: no window tables, no warm-up MSM\n"); }
+    ~TableMode() { (void)mnt753_msm_set_window_table(old); }
+  } table_mode(one_shot_mode());
   groth16_params* p = new groth16_params(path);
   const int n_dev = std::max(1, mnt753_device_count());
   LoadTrace lt;

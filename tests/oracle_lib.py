@@ -8,6 +8,25 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = None
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def need_ref(*binaries):
+    """Paths of oracle/_ref/<binary> (the reference's own sources compiled by oracle/build_ref.sh in the build container; the files
+    travel to the GPU box with the snapshot).  For a GPU test a MISSING reference binary is a FAILURE, not a skip: a snapshot that lost
+    oracle/_ref would otherwise go green with its strongest evidence -- the live differential tests, the reference's unchanged driver
+    over the wrapper, libff's own multi_exp at size, the reference's verifier -- silently gone.  MNT753_ALLOW_MISSING_REF=1 is the one
+    opt-out, for a GPU host that has neither /root/reference nor a copy of oracle/_ref (the test is then skipped and says so)."""
+    import pytest
+    paths = [os.path.join(REF_DIR, b) for b in binaries]
+    missing = [b for b, q in zip(binaries, paths) if not os.access(q, os.X_OK)]
+    if missing:
+        msg = ("oracle/_ref/{" + ",".join(missing) + "} missing: build them in the container (make -C oracle ref, tools/dropin_check.sh -- "
+               "__graft_entry__.build() does both where /root/reference exists); they travel to the GPU box with the snapshot")
+        if os.environ.get("MNT753_ALLOW_MISSING_REF") == "1":
+            pytest.skip(msg + " [MNT753_ALLOW_MISSING_REF=1]")
+        pytest.fail(msg)
+    return paths[0] if len(paths) == 1 else paths
 
 
 def lib():

@@ -45,7 +45,8 @@ def test_full_prove_matches_reference_hash(gpu, key, tmp_path):
     assert os.path.getsize(params) == e["params_bytes"] and os.path.getsize(inp) == e["input_bytes"]
     assert sha256_file(params) == e["params_sha256"], "synthetic parameter file differs from the one the reference proved"
     assert sha256_file(inp) == e["input_sha256"], "synthetic input file differs from the one the reference proved"
-    runs = [([], {}), (["--unfused-h", "--ref-order"], {})]
+    # [] = the CLI as the reference is invoked: a one-shot prover, no window tables (host/main.cpp); --tables = what a resident prover runs
+    runs = [([], {}), (["--unfused-h", "--ref-order", "--tables"], {})]
     if key in ("MNT6753_2p15", "MNT4753_2p20"):
         # BASELINE configs[4] and the north-star split at its widest: every parameter vector cut into EIGHT contiguous slices
         # (multiexp.tcc:417-431; 4096 / 131072 points per slice), one base set, window table, input loader and stream per

@@ -127,8 +127,7 @@ def test_prove_from_constraint_system_and_verify(gpu, curve, tmp_path):
     r = subprocess.run([EXE, NAME[curve], "complete", fx(curve, "keys.bin"), fx(curve, "witness.bin"), chal, full, "--s-seed", "99"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    if not os.access(REF, os.X_OK):
-        pytest.skip("oracle/_ref/ref_groth16 not built (needs the reference tree at build time)")
+    O.need_ref("ref_groth16")                     # missing = failure on a GPU box (tests/oracle_lib.py)
     v = subprocess.run([REF, "verify", NAME[curve], os.path.dirname(fx(curve, "vk.txt")), full], capture_output=True, text=True)
     assert v.returncode == 0 and "VERIFIED" in v.stdout, v.stdout + v.stderr
     # a wrong witness file size is refused before anything is allocated

@@ -25,9 +25,7 @@ PIECEWISE_HIP = os.path.join(REF, "piecewise_hip")
 
 
 def need_ref():
-    for b in ("generate_parameters", "main"):
-        if not os.access(os.path.join(REF, b), os.X_OK):
-            pytest.skip(f"oracle/_ref/{b} not built (oracle/build_ref.sh needs /root/reference: build container only; the files travel to the GPU box)")
+    O.need_ref("generate_parameters", "main", "piecewise_hip")     # missing = failure on a GPU box (tests/oracle_lib.py)
 
 
 def generate(work, fast):
@@ -71,12 +69,12 @@ def test_fresh_fast_parameter_sets_same_bytes_as_the_reference(gpu, tmp_path):
         for tag, flags, env in CONFIGS:
             out, _ = prove_hip(work, curve, tag, flags, env)
             assert filecmp.cmp(out, ref_out, shallow=False), (curve, tag)
-        if os.access(PIECEWISE_HIP, os.X_OK):   # the reference's own driver text over the MI355X wrapper (tools/dropin_check.sh)
-            out = os.path.join(work, f"{curve}-output-dropin")
-            r = subprocess.run([PIECEWISE_HIP, curve, "compute", os.path.join(work, f"{curve}-parameters"), os.path.join(work, f"{curve}-input"), out],
-                               capture_output=True, text=True)
-            assert r.returncode == 0, r.stderr[-2000:]
-            assert filecmp.cmp(out, ref_out, shallow=False), (curve, "dropin")
+        # the reference's own driver text over the MI355X wrapper (tools/dropin_check.sh)
+        out = os.path.join(work, f"{curve}-output-dropin")
+        r = subprocess.run([PIECEWISE_HIP, curve, "compute", os.path.join(work, f"{curve}-parameters"), os.path.join(work, f"{curve}-input"), out],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert filecmp.cmp(out, ref_out, shallow=False), (curve, "dropin")
 
 
 @pytest.mark.skipif(os.environ.get("MNT753_REAL_PARAMS") != "1", reason="opt-in (MNT753_REAL_PARAMS=1): the generator's full sizes take minutes of host time")

@@ -252,9 +252,7 @@ def test_full_size_2pow20_g1_vs_libff_multi_exp(gpu, tmp_path):
     multi_exp_with_mixed_addition<BDLO12> (oracle/_ref/ref_msm_bench = our driver around the reference's multiexp.tcc:443-496, compiled
     by oracle/build_ref.sh; chunks = host threads as B::multiexp_G1 runs it) -- the check bench.py's cpu_baseline leg also makes, here
     as a test.  The pairs carry what a real witness carries: zero and one scalars and an identity base."""
-    ref = os.path.join(O.ROOT, "oracle", "_ref", "ref_msm_bench")
-    if not os.access(ref, os.X_OK):
-        pytest.fail("oracle/_ref/ref_msm_bench is missing: build it in the container (make -C oracle ref); it travels with the snapshot")
+    ref = O.need_ref("ref_msm_bench")             # missing = failure on a GPU box (tests/oracle_lib.py)
     n = 1 << 20
     pts = gpu.synth_points(0, 1, 42, n)
     sc = gpu.synth_scalars(0, 45, n)
@@ -276,9 +274,7 @@ def test_full_size_2pow20_g1_vs_libff_multi_exp(gpu, tmp_path):
 
 def libff_msm(tmp_path, curve, group, pts, sc, timeout=1400):
     """the affine result words of libff's multi_exp_with_mixed_addition<BDLO12> over the same (base, scalar) pairs (oracle/_ref/ref_msm_bench)"""
-    ref = os.path.join(O.ROOT, "oracle", "_ref", "ref_msm_bench")
-    if not os.access(ref, os.X_OK):
-        pytest.fail("oracle/_ref/ref_msm_bench is missing: build it in the container (make -C oracle ref); it travels with the snapshot")
+    ref = O.need_ref("ref_msm_bench")             # missing = failure on a GPU box (tests/oracle_lib.py)
     path = tmp_path / "pairs.bin"
     with open(path, "wb") as f:
         pts.tofile(f); sc.tofile(f)
@@ -308,10 +304,11 @@ def test_g2_and_mnt6753_at_size_vs_libff_multi_exp(gpu, tmp_path, curve, group, 
 
 
 @pytest.mark.timeout(3000)
-@pytest.mark.skipif(os.environ.get("MNT753_LIBFF_G2_FULL") != "1", reason="opt-in (MNT753_LIBFF_G2_FULL=1): libff's 2^20-point G2 MSM is ~2 min on 256 host threads")
+@pytest.mark.skipif(os.environ.get("MNT753_LIBFF_G2_FULL", "1" if (os.cpu_count() or 1) >= 64 else "0") != "1",
+                    reason="libff's 2^20-point G2 MSM is ~90 s on 256 host threads and an hour on eight: on by default from 64 host threads, MNT753_LIBFF_G2_FULL=1 / 0 overrides")
 def test_full_size_2pow20_g2_vs_libff_multi_exp(gpu, tmp_path):
     """BASELINE config[1]'s G2 MSM, all 2^20 pairs, against libff's own multi_exp_with_mixed_addition (B::multiexp_G2,
-    prover_reference_functions.cpp:257-265).  The round's run is recorded in profiles/."""
+    prover_reference_functions.cpp:257-265).  Runs by default on the GPU box (256 host threads: 88 s)."""
     n = 1 << 20
     pts = gpu.synth_points(0, 2, 242, n)
     sc = gpu.synth_scalars(0, 245, n)

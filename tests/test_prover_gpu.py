@@ -19,7 +19,8 @@ NAME = {0: "MNT4753", 1: "MNT6753"}
 
 @pytest.mark.parametrize("curve", [0, 1])
 @pytest.mark.parametrize("flags", [[], ["--unfused-h"], ["--ref-order"], ["--unfused-h", "--ref-order"], ["--unfused-c"], ["--c-last"],
-                                   ["--unfused-c", "--h-last"], ["--repeat", "2"], ["--ref-order", "--touch-all", "--repeat", "2"]])
+                                   ["--unfused-c", "--h-last"], ["--repeat", "2"], ["--ref-order", "--touch-all", "--repeat", "2"],
+                                   ["--tables"], ["--one-shot", "--repeat", "2"]])
 def test_reference_proof_files(gpu, curve, flags, tmp_path):
     params, inp, expected = G.e2e_paths(curve)
     out = str(tmp_path / "proof.bin")
@@ -27,6 +28,10 @@ def test_reference_proof_files(gpu, curve, flags, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "Total time from input to output" in r.stdout
     assert filecmp.cmp(out, expected, shallow=False)
+    # the one-shot policy (host/main.cpp): one job on one device and no --repeat / --serve = the reference's CLI (libsnark/main.cpp:274-293),
+    # no window tables and no warm-up MSM; a resident prover keeps both; --tables / --one-shot force either
+    one_shot = ("--one-shot" in flags) or ("--repeat" not in flags and "--tables" not in flags)
+    assert ("one-shot prover" in r.stdout) == one_shot, r.stdout
 
 
 @pytest.mark.parametrize("curve", [0, 1])
@@ -39,7 +44,8 @@ def test_alternative_kernel_paths_write_the_same_proof(gpu, curve, env, tmp_path
     lane, no window table.  Every one must reproduce the reference's proof bytes."""
     params, inp, expected = G.e2e_paths(curve)
     out = str(tmp_path / "proof.bin")
-    r = subprocess.run([EXE, NAME[curve], "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, **env))
+    # --tables: a single job would otherwise run as a one-shot prover, without the window tables these switches also have to hold under
+    r = subprocess.run([EXE, NAME[curve], "compute", params, inp, out, "--tables"], capture_output=True, text=True, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr
     assert filecmp.cmp(out, expected, shallow=False)
 
@@ -97,9 +103,7 @@ def test_multi_gpu_driver_reference_proofs(gpu, curve, world, tmp_path):
 def test_reference_driver_unchanged(gpu, curve, tmp_path):
     """oracle/_ref/piecewise_hip = the reference's own cuda_prover_piecewise.cu driver (lines 14-120, untouched) compiled over
     include/prover_hip_functions.hpp by tools/dropin_check.sh in the build container: same proof bytes as the reference."""
-    exe = os.path.join(O.ROOT, "oracle", "_ref", "piecewise_hip")
-    if not os.access(exe, os.X_OK):
-        pytest.skip("oracle/_ref/piecewise_hip not built (tools/dropin_check.sh needs the reference tree)")
+    exe = O.need_ref("piecewise_hip")             # missing = failure on a GPU box (tests/oracle_lib.py)
     params, inp, expected = G.e2e_paths(curve)
     out = str(tmp_path / "proof.bin")
     r = subprocess.run([exe, NAME[curve], "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_TRACE="1"))

@@ -118,6 +118,46 @@ def test_r1cs_front_end_and_completion_clean_under_sanitizers(san, kind, tmp_pat
         run(san[kind], [NAME[curve], "complete", os.path.join(d, "keys.bin"), os.path.join(d, "input.bin"), os.path.join(d, "challenge.bin"), str(tmp_path / "full")])
 
 
+def test_one_shot_policy_reaches_the_c_abi(san, tmp_path):
+    """host/main.cpp: one job on one device without --repeat / --serve is a one-proof process like the reference's CLI
+    (libsnark/main.cpp:274-293) -- B::one_shot(true), i.e. mnt753_msm_set_window_table(0) around read_params and no warm-up MSM; several
+    jobs, --repeat, --serve, --gpus or --tables keep the tables; --one-shot forces them off.  The stub logs the mode it is handed."""
+    params, inp, _ = G.e2e_paths(1)
+    out = str(tmp_path / "o")
+    def modes(flags, extra_env=None):
+        env = dict(os.environ, MNT753_STUB_LOG="1", ASAN_OPTIONS="detect_leaks=1", **(extra_env or {}))
+        r = subprocess.run([san["asan"], "MNT6753", "compute", params, inp, out] + flags, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr, r.stderr[-2000:]
+        first = [l for l in r.stderr.splitlines() if l.startswith("stub: window table mode")]
+        return (first[0].rsplit(" ", 1)[1] if first else None), r.stdout
+    m, so = modes([])
+    assert m == "0" and "one-shot prover" in so
+    for flags in (["--repeat", "2"], ["--tables"], ["--gpus", "2"], [inp, str(tmp_path / "o2")]):
+        m, so = modes(flags)
+        assert m == "1" and "one-shot prover" not in so, flags
+    m, so = modes(["--one-shot", "--repeat", "2"])
+    assert m == "0"
+    m, so = modes([], {"MNT753_ONE_SHOT": "0"})
+    assert m == "1"
+
+
+def test_self_test_is_run_once_and_is_fatal(san, tmp_path):
+    """B::init_public_params runs mnt753_self_test(1) once per process (the stub logs the call; the arithmetic behind it is a GPU test,
+    tests/test_selftest_gpu.py); a failure ends the prover before it reads a parameter; MNT753_SELFTEST=0 skips it."""
+    params, inp, _ = G.e2e_paths(0)
+    out = str(tmp_path / "o")
+    def go(extra):
+        env = dict(os.environ, MNT753_STUB_LOG="1", ASAN_OPTIONS="detect_leaks=0", **extra)
+        return subprocess.run([san["asan"], "MNT4753", "compute", params, inp, out, "--repeat", "2"], capture_output=True, text=True, env=env, timeout=600)
+    r = go({})
+    assert r.returncode == 0 and r.stderr.count("stub: self-test level 1") == 1, r.stderr[-800:]
+    r = go({"MNT753_SELFTEST": "0"})
+    assert r.returncode == 0 and "stub: self-test" not in r.stderr
+    r = go({"MNT753_STUB_SELFTEST_FAILS": "1"})
+    assert r.returncode == 1 and "mnt753_self_test" in r.stderr and "Sanitizer" not in r.stderr, r.stderr[-800:]
+    assert "load params" not in r.stdout
+
+
 def test_error_paths_clean_under_asan(san, tmp_path):
     """Every way the CLI can fail: no invalid access on the way out.  Leak checking is off here only: the wrapper keeps the
     reference's raw-pointer interface (B::read_params returns a `new`-ed object the driver deletes at the end), so an exception that
@@ -132,6 +172,13 @@ def test_error_paths_clean_under_asan(san, tmp_path):
     run_err(exe, ["BN128", "compute", params, inp, out], expect_rc=2)
     run_err(exe, ["MNT4753"], expect_rc=2)
     run_err(exe, ["MNT4753", "compute", params, inp, out, "--gpus", "99"], expect_rc=1)
+    # an option this prover does not have (--point-cus left in round 5), an option that lost its argument, an input without its output:
+    # refused with exit code 2, not parsed as a job pair or silently dropped (round-5 advice)
+    r = run_err(exe, ["MNT4753", "compute", params, inp, out, "--point-cus", "240"], expect_rc=2)
+    assert "unknown option --point-cus" in r.stderr
+    run_err(exe, ["MNT4753", "compute", params, inp, out, "--repeat"], expect_rc=2)
+    r = run_err(exe, ["MNT4753", "compute", params, inp, out, inp], expect_rc=2)
+    assert "without an output path" in r.stderr
     raw = bytearray(open(params, "rb").read())
     (tmp_path / "trunc").write_bytes(bytes(raw[:-8]))
     run_err(exe, ["MNT4753", "compute", str(tmp_path / "trunc"), inp, out], expect_rc=1)

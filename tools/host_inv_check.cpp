@@ -48,6 +48,17 @@ template <int M> bool base(const char* name, const char* golden) {
     if (!(inv == xs[i].inverse_fermat())) { printf("%s: value %zu differs from Fermat\n", name, i); ok = false; break; }
     if (!xs[i].is_zero() && !(inv * xs[i] == one)) { printf("%s: value %zu: a * a^-1 != 1\n", name, i); ok = false; break; }
   }
+  // non-canonical stored words (from_words is a raw copy): l = p, 2p, p + 1 must behave as 0, 0, 1 and must terminate
+  {
+    uint64_t w[12];
+    memcpy(w, mnt753::FPC[M].p64, sizeof(w));
+    if (!H::from_words(w).inverse().is_zero()) { printf("%s: inverse of the stored word p is not 0\n", name); ok = false; }
+    { unsigned __int128 c = 0; for (int i = 0; i < 12; ++i) { c += (unsigned __int128)mnt753::FPC[M].p64[i] * 2; w[i] = (uint64_t)c; c >>= 64; } }
+    if (!H::from_words(w).inverse().is_zero()) { printf("%s: inverse of the stored word 2p is not 0\n", name); ok = false; }
+    memcpy(w, mnt753::FPC[M].p64, sizeof(w)); w[0] += 1;               // p is odd: no carry
+    H one_raw = H::zero(); one_raw.l[0] = 1;
+    if (!(H::from_words(w).inverse() == one_raw.inverse())) { printf("%s: inverse of the stored word p + 1 differs from that of 1\n", name); ok = false; }
+  }
   auto t0 = clk::now();
   H acc = H::zero();
   for (int i = 0; i < 200; ++i) acc = acc + xs[(size_t)i].inverse();
