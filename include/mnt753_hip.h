@@ -70,12 +70,14 @@ int mnt753_init_devices(int n_devices);
  * (csrc/mnt753_selftest_data.h, minted by tools/gen_selftest_data.py through oracle/_ref -- data, none of the oracle's code).
  * level 0: the host tails (point decoding, addition, doubling, affine output) on one libff record per group; level 1: plus a 256-point
  * MSM per (curve, group) -- with and without the batched-affine levels of the large sets in front of it -- and compute_H on a 2^8
- * domain per curve (~20 ms); level 2: plus the same MSMs over a window table (~0.1 s).  0 if everything agrees, MNT753_ESELFTEST (and
+ * domain per curve (~0.15 s for both curves, most of it the allocations of the small base sets); level 2: plus the same MSMs over a window table (~0.35 s).  0 if everything agrees, MNT753_ESELFTEST (and
  * a message naming the check) if one word differs, another code if a call failed.  Why: a proof is only as sound as the build that
  * computed it, and the compiler has miscompiled kernels of this library before; the reference carries a check of the same
- * purpose around its prover (libsnark/main.cpp:295-343).  B::init_public_params runs level 1 once per process (MNT753_SELFTEST=0
+ * purpose around its prover (libsnark/main.cpp:295-343).  B::init_public_params runs level 1 for its curve once per process (MNT753_SELFTEST=0
  * skips it, MNT753_SELFTEST=2 raises it); `main_hip <curve> self-test` runs level 2. */
 int mnt753_self_test(int level);
+/* the same for one curve (MNT753_CURVE_MNT4753 / MNT753_CURVE_MNT6753): what B::init_public_params of that curve's class runs */
+int mnt753_self_test_curve(int curve, int level);
 int mnt753_device_count(void);
 int mnt753_set_device(int logical_device);
 int mnt753_get_device(void);   /* the calling thread's current logical device (0 before mnt753_set_device) */
@@ -117,6 +119,9 @@ int mnt753_copy_d2h(void* dst, const void* dev_src, size_t bytes);
 int mnt753_copy_d2d(void* dev_dst, const void* dev_src, size_t bytes);
 int mnt753_dev_memset(void* dev_dst, int value, size_t bytes);
 int mnt753_sync(void* stream);
+/* free / total memory of the calling thread's current device (hipMemGetInfo): the wrapper prints what a parameter set occupies
+ * (window tables, workspaces, the pooled buffers of the batched-affine levels) under MNT753_TRACE_LOAD=1 */
+int mnt753_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 /* Stream `bytes` of file `path` starting at `file_offset` into device memory (double-buffered pinned staging, reads
  * overlap the H2D copies); blocks the calling thread until the data is on the device.  Thread-safe: the wrapper's input
  * loader calls it from a background thread while the main thread launches kernels (replaces the 6.3 M fread calls of
@@ -160,7 +165,8 @@ int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first);
 
 /* Window tables of the base sets created FROM NOW ON: mode 1 (default) -- a set of 4096 points or more gets the table of its window
  * multiples 2^(cw) P_i at creation (0.33 s of kernels per 2^20 G1 points, 1.3 s for 2^20 G2 points; an MSM over it then takes
- * 23.7 ms instead of 38-43); mode 0 -- no tables: what a process that will prove ONCE wants, because the reference's CLI is such a
+ * 23.7 ms instead of 38-43); mode 0 -- no tables and no batched-affine levels (whose buffers are tens of GB to allocate): what a
+ * process that will prove ONCE wants, because the reference's CLI is such a
  * process (libsnark/main.cpp:196-203 loads the parameters per invocation, :274-293) and a table never pays for itself in one proof.
  * The wrapper's B::one_shot / main_hip's default for a single job use it.  MNT753_MSM_PRECOMP=0 / 1 in the environment overrides
  * both.  Returns the previous mode. */

@@ -65,7 +65,9 @@ def lib():
         "mnt753_msm_finish": (i, [vp, u64p]),
         "mnt753_msm_set_window_bits": (i, [i]),
         "mnt753_msm_set_window_table": (i, [i]),
+        "mnt753_dev_mem_info": (i, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "mnt753_self_test": (i, [i]),
+        "mnt753_self_test_curve": (i, [i, i]),
         "mnt753_msm_order_after": (i, [vp, vp]),
         "mnt753_msm_last_timing": (i, [C.POINTER(C.c_float)]),
         "mnt753_msm_last_plan": (i, [C.POINTER(C.c_int)]),
@@ -149,9 +151,12 @@ def init(device=0):
     _check(lib().mnt753_init(int(device)), "mnt753_init")
 
 
-def self_test(level=1):
-    """mnt753_self_test: the known answers embedded in the library (include/mnt753_hip.h); raises Mnt753Error on a mismatch"""
-    _check(lib().mnt753_self_test(level), "mnt753_self_test")
+def self_test(level=1, curve=None):
+    """mnt753_self_test / _curve: the known answers embedded in the library (include/mnt753_hip.h); raises Mnt753Error on a mismatch"""
+    if curve is None:
+        _check(lib().mnt753_self_test(level), "mnt753_self_test")
+    else:
+        _check(lib().mnt753_self_test_curve(curve, level), "mnt753_self_test")
 
 
 def exchange_points(blocks):

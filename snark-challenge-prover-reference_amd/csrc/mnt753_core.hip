@@ -330,6 +330,14 @@ int mnt753_dev_memset(void* dev_dst, int value, size_t bytes) {
   HIP_TRY(hipMemsetAsync(dev_dst, value, bytes, nullptr));
   return 0;
 }
+int mnt753_dev_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  if (int rc = require_device()) return rc;
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return 0;
+}
 int mnt753_load_file_to_device(const char* path, size_t file_offset, size_t bytes, void* dev_dst) {
   if (int rc = require_device()) return rc;
   if (!path || (bytes && !dev_dst)) return set_error(MNT753_EINVAL, "load_file_to_device: null argument");

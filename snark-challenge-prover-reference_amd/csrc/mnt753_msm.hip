@@ -12,6 +12,7 @@
 namespace mnt753 {
 int g_window_bits_override = 0;
 int g_force_pair_levels = -1, g_force_irr_levels = -1;
+PairPool g_pair_pool[PAIR_POOL_DEVICES];
 int g_window_table_mode = 1;   // mnt753_msm_set_window_table: 1 = tables for base sets of 4096 points and more, 0 = none
 float g_last_timing[5] = {0, 0, 0, 0, 0};
 int g_last_plan[4] = {0, 0, 0, 0};
@@ -55,7 +56,7 @@ int mnt753_bases_create(int curve, int group, const uint64_t* affine, int on_dev
   if (create_msm_stream(&b->own_stream, group) != hipSuccess) b->own_stream = nullptr;
   if (hipEventCreateWithFlags(&b->ev_dep, hipEventDisableTiming) != hipSuccess) b->ev_dep = nullptr;
   (void)hipGetLastError();
-  { std::lock_guard<std::mutex> l(g_sets_mu); g_sets.insert(b); }
+  { std::lock_guard<std::mutex> l(g_sets_mu); g_sets.insert(b); ++pair_pool_of(b).refs; b->registered = 1; }
   *out = b;
   return 0;
 }
@@ -71,6 +72,17 @@ int mnt753_bases_free(mnt753_bases* b) {
       if (o->after_owner == b) { o->after_ev = nullptr; o->after_owner = nullptr; }   // its event is about to be destroyed
   }
   msm_free_workspace(b);
+  {
+    // the last base set of a device gives the pooled level buffers back
+    std::lock_guard<std::mutex> l(g_sets_mu);
+    PairPool& pool = pair_pool_of(b);
+    if (pool.refs > 0 && b->registered) --pool.refs;
+    if (pool.refs == 0) {
+      for (int i = 0; i < 4; ++i) { if (pool.buf[i]) (void)hipFree(pool.buf[i]); pool.buf[i] = nullptr; pool.cap[i] = 0; }
+      if (pool.last_acc) { (void)hipEventDestroy(pool.last_acc); pool.last_acc = nullptr; }
+      pool.used = false;
+    }
+  }
   if (b->d_aff) (void)hipFree(b->d_aff);
   if (b->d_inf) (void)hipFree(b->d_inf);
   for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);

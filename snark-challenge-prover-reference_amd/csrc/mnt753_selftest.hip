@@ -12,9 +12,10 @@
 //            one regular and one irregular batched-affine level in front of the accumulation (the kernels of the large sets);
 //            per curve compute_H on a 2^8 domain against libfqfft's call sequence
 //   level 2  + the same MSMs over a window table (the doubling chains of k_precompute_windows: ~20 ms per group, latency of one chain)
-// B::init_public_params runs level 1 (~20 ms); `main_hip <curve> self-test` runs level 2.  MNT753_SELFTEST=0 skips it.
-// MNT753_SELFTEST_CORRUPT=<k> (tests) flips one bit in the expected words of check k (8 host checks, then per curve 2 x 2 MSM checks --
-// 4 x 2 at level 2 -- and compute_H: 18 checks at level 1, 26 at level 2), which must then be reported.
+// B::init_public_params runs level 1 for ITS curve (mnt753_self_test_curve: ~75 ms, most of it the hipMallocs of four small base sets);
+// `main_hip <curve> self-test` runs level 2 for both.  MNT753_SELFTEST=0 skips it.
+// MNT753_SELFTEST_CORRUPT=<k> (tests) flips one bit in the expected words of check k (both curves: 8 host checks, then per curve 2 x 2 MSM checks --
+// 4 x 2 at level 2 -- and compute_H: 18 checks at level 1, 26 at level 2; one curve: 4 + 5 = 9 at level 1), which must then be reported.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,7 +86,7 @@ int msm_checks(Ctx& c, int curve, int group, int level) {
     ~Restore() { g_force_pair_levels = pair; g_force_irr_levels = irr; g_window_table_mode = table; }
   } restore;
   for (int pass = 0; pass < (level >= 2 ? 2 : 1); ++pass) {
-    g_window_table_mode = pass == 0 ? 0 : 2;          // 2: a table whatever the size of the set (this file only)
+    g_window_table_mode = pass == 0 ? 1 : 2;          // 1: no table for a set this small; 2: a table whatever the size (this file only)
     mnt753_bases* bs = nullptr;
     if (int rc = mnt753_bases_create(curve, group, pts.data(), 0, n, &bs)) return rc;
     int rc = 0;
@@ -136,16 +137,17 @@ int h_check(Ctx& c, int curve) {
 }
 }  // namespace
 
-extern "C" int mnt753_self_test(int level) {
-  if (level < 0 || level > 2) return set_error(MNT753_EINVAL, "self_test: level 0, 1 or 2");
+// curve: MNT753_CURVE_MNT4753 / _MNT6753, or -1 for both.  Check numbers (MNT753_SELFTEST_CORRUPT) count in call order over the
+// curves that run: per curve 4 host checks, then 2 x 2 MSM checks (4 x 2 at level 2) and compute_H.
+static int self_test_curves(int curve_lo, int curve_hi, int level) {
   Ctx c;
   if (const char* e = getenv("MNT753_SELFTEST_CORRUPT")) c.corrupt = atoi(e);
-  for (int curve = 0; curve < 2; ++curve)
+  for (int curve = curve_lo; curve <= curve_hi; ++curve)
     for (int group = 1; group <= 2; ++group)
       if (int rc = group_record(c, curve, group)) return rc;
   if (level >= 1) {
     if (int rc = require_device()) return rc;
-    for (int curve = 0; curve < 2; ++curve) {
+    for (int curve = curve_lo; curve <= curve_hi; ++curve) {
       for (int group = 1; group <= 2; ++group)
         if (int rc = msm_checks(c, curve, group, level)) return rc;
       if (int rc = h_check(c, curve)) return rc;
@@ -153,4 +155,13 @@ extern "C" int mnt753_self_test(int level) {
   }
   if (!c.failed.empty()) return set_error(MNT753_ESELFTEST, c.failed.c_str());
   return 0;
+}
+
+extern "C" int mnt753_self_test(int level) {
+  if (level < 0 || level > 2) return set_error(MNT753_EINVAL, "self_test: level 0, 1 or 2");
+  return self_test_curves(0, 1, level);
+}
+extern "C" int mnt753_self_test_curve(int curve, int level) {
+  if (level < 0 || level > 2 || curve < 0 || curve > 1) return set_error(MNT753_EINVAL, "self_test_curve: curve 0 or 1, level 0, 1 or 2");
+  return self_test_curves(curve, curve, level);
 }

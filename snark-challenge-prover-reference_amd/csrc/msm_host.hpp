@@ -23,6 +23,7 @@ using namespace mnt753;
 namespace mnt753 {
 extern int g_window_bits_override;
 extern int g_window_table_mode;
+// (PairPool, the device's pooled buffers of the batched-affine levels: msm_types.hpp)
 extern int g_force_pair_levels, g_force_irr_levels;   // >= 0: mnt753_self_test puts the level kernels onto its small sets (as MNT753_MSM_PAIR / _IRR do for the tests)
 extern float g_last_timing[5];
 extern int g_last_plan[4];
@@ -129,7 +130,8 @@ int point_lanes() {
   else return CS::F::LANES;
 }
 void free_pair_ws(mnt753_bases* b) {
-  void* ptrs[] = {b->d_pair_ws, b->d_fix, b->d_gen, b->d_pairpts[0], b->d_pairpts[1], b->d_sorted2, b->d_irr_offs[0], b->d_irr_offs[1], b->d_irr_src, b->d_irr_blocks};
+  // (d_pairpts, d_sorted2, d_pair_ws belong to the device's PairPool: only forgotten here)
+  void* ptrs[] = {b->d_fix, b->d_gen, b->d_irr_offs[0], b->d_irr_offs[1], b->d_irr_src, b->d_irr_blocks};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   b->d_pair_ws = b->d_fix = b->d_gen = b->d_sorted2 = nullptr;
   b->d_irr_offs[0] = b->d_irr_offs[1] = b->d_irr_src = b->d_irr_blocks = nullptr;
@@ -276,6 +278,11 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
   }
   // Workspace and events of a full-size MSM over this set are allocated here, at parameter-load time, so that the
   // first mnt753_msm* call on the set does not start with ~20 hipMallocs.
+  // A set of a one-proof process (mode 0, no table) also runs WITHOUT the batched-affine levels: their buffers are 14 GB per 2^20 G1
+  // points without a table (43 GB for the 3 x 2^20 points of H | L | B1), which the driver hands over at ~30 GB/s -- 1.5 s of a
+  // parameter load measured in round 6, and as much again inside the first proof when the memory had just been another process's --
+  // to save ~0.05 s on the one proof that will ever run over the set.
+  if (g_window_table_mode == 0 && !want_table) b->no_pair = 1;
   {
     MsmPlan p = plan_for<C>(b, n);
     if (p.pair_levels > 0 && ensure_pair_ws_for<C>(b, p, n) != 0) {
@@ -377,23 +384,47 @@ template <class V, class C>
 int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p, size_t n) {
   if constexpr (V::F::DEG == 1 || V::F::LANES > 1) {
     const uint64_t cap1 = pair_cap1(p, n);
-    if (b->pair_cap >= cap1 && b->pair_buckets >= p.n_buckets) return 0;
     const uint64_t capA = std::max<uint64_t>(cap1, b->pair_cap);
     const size_t nbA = std::max<size_t>(p.n_buckets, b->pair_buckets);
-    free_pair_ws(b);
-    HIP_TRY(hipMalloc(&b->d_fix, sizeof(uint32_t) * nbA));
-    HIP_TRY(hipMalloc(&b->d_gen, sizeof(uint32_t) * aff_words<V>()));
     // rows of a level: row-major (last level, 224 B x DEG per slot) or four blocked planes (same bytes + rounding per plane)
     const size_t slack = 4 * 64 * 7 * 16 * 2;
-    HIP_TRY(hipMalloc(&b->d_pairpts[0], sizeof(uint32_t) * aff_words<V>() * capA + slack * V::F::DEG));             // levels 1, 3, 5
-    // (an irregular level writes at most half its input plus one slot per bucket: the buckets' worth of room covers it at any depth)
-    HIP_TRY(hipMalloc(&b->d_pairpts[1], sizeof(uint32_t) * aff_words<V>() * (capA / 2 + nbA + 1) + slack * V::F::DEG));   // levels 2, 4, 6
-    HIP_TRY(hipMalloc(&b->d_sorted2, sizeof(uint32_t) * capA));                                 // entry list of the last level
+    // the device's pooled buffers: grown to what THIS set needs (bytes: the sets of a device differ in row width), then bound
+    {
+      PairPool& pool = pair_pool_of(b);
+      const size_t need[4] = {sizeof(uint32_t) * aff_words<V>() * capA + slack * V::F::DEG,                      // levels 1, 3, 5
+                              // (an irregular level writes at most half its input plus one slot per bucket: the buckets' worth of room covers it at any depth)
+                              sizeof(uint32_t) * aff_words<V>() * (capA / 2 + nbA + 1) + slack * V::F::DEG,       // levels 2, 4, 6
+                              sizeof(uint32_t) * capA,                                                            // entry list of the last level
+                              16 * blk_quads((uint64_t)capA * V::F::LANES + 64)};                                 // one prefix product per slot (blocked)
+      bool grow = false;
+      for (int i = 0; i < 4; ++i) grow = grow || need[i] > pool.cap[i];
+      if (grow) {
+        if (pool.used) HIP_TRY(hipEventSynchronize(pool.last_acc));   // nobody reads the old buffers behind its accumulate kernel
+        for (int i = 0; i < 4; ++i) {
+          if (need[i] <= pool.cap[i]) continue;
+          if (pool.buf[i]) { (void)hipFree(pool.buf[i]); pool.buf[i] = nullptr; pool.cap[i] = 0; }
+          HIP_TRY(hipMalloc(&pool.buf[i], need[i]));
+          pool.cap[i] = need[i];
+        }
+      }
+      b->d_pairpts[0] = static_cast<uint32_t*>(pool.buf[0]);
+      b->d_pairpts[1] = static_cast<uint32_t*>(pool.buf[1]);
+      b->d_sorted2 = static_cast<uint32_t*>(pool.buf[2]);
+      b->d_pair_ws = static_cast<uint32_t*>(pool.buf[3]);
+    }
+    if (b->pair_cap >= cap1 && b->pair_buckets >= p.n_buckets) return 0;
+    // the set's own small buffers
+    free_pair_ws(b);
+    b->d_pairpts[0] = static_cast<uint32_t*>(pair_pool_of(b).buf[0]);
+    b->d_pairpts[1] = static_cast<uint32_t*>(pair_pool_of(b).buf[1]);
+    b->d_sorted2 = static_cast<uint32_t*>(pair_pool_of(b).buf[2]);
+    b->d_pair_ws = static_cast<uint32_t*>(pair_pool_of(b).buf[3]);
+    HIP_TRY(hipMalloc(&b->d_fix, sizeof(uint32_t) * nbA));
+    HIP_TRY(hipMalloc(&b->d_gen, sizeof(uint32_t) * aff_words<V>()));
     HIP_TRY(hipMalloc(&b->d_irr_offs[0], sizeof(uint32_t) * (nbA + 1)));
     HIP_TRY(hipMalloc(&b->d_irr_offs[1], sizeof(uint32_t) * (nbA + 1)));
     HIP_TRY(hipMalloc(&b->d_irr_src, sizeof(uint32_t) * (capA / 2 + nbA + 64)));
     HIP_TRY(hipMalloc(&b->d_irr_blocks, sizeof(uint32_t) * (nbA / IRR_BLOCK + 4)));
-    HIP_TRY(hipMalloc(&b->d_pair_ws, 16 * blk_quads((uint64_t)capA * V::F::LANES + 64)));       // one prefix product per slot (blocked)
     // D: the group generator in device form (wire constant -> k_bases_to_internal)
     uint32_t* wire = nullptr; uint8_t* inf = nullptr;
     const size_t gen_bytes = 192 * (size_t)C::F::DEG;
@@ -453,6 +484,9 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
     const uint32_t max_lanes = std::min<uint32_t>(machine_lanes(V::F::LANES), V::F::LANES == 3 ? PAIR_MAX_LANES / 3u : PAIR_MAX_LANES / (uint32_t)V::F::LANES);
     const uint32_t min_B = PAIR_MIN_B;
     if (int rc = ensure_pair_ws<V, C>(b, p, n)) return rc;
+    // the device's pooled level buffers: ours once the accumulate kernel of the MSM that used them last has ended
+    PairPool& pool = pair_pool_of(b);
+    if (pool.used) HIP_TRY(hipStreamWaitEvent(st, pool.last_acc, 0));
     HIP_TRY(hipMemsetAsync(b->d_fix, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
     uint64_t cap = 2 * pair_cap1(p, n);        // worst-case entries of the padded list
     const uint4* src_planes = nullptr;
@@ -550,6 +584,9 @@ int pair_and_accumulate(const MsmPlan& p, size_t n, hipStream_t st, const uint32
     const uint32_t T2 = (uint32_t)std::max<uint64_t>((cap + lanes_acc - 1) / lanes_acc, 8);
     hipLaunchKernelGGL((k_bucket_accumulate<V, true>), dim3(blocks_for<typename V::F>(lanes_acc)), dim3(256), 0, st, src, b->d_sorted2,
                        offs_acc, p.n_buckets, b->d_buckets, b->d_edges, b->d_edge_bucket, T2, lanes_acc, src_stride);
+    if (!pool.last_acc) HIP_TRY(hipEventCreateWithFlags(&pool.last_acc, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(pool.last_acc, st));
+    pool.used = true;
     *acc_lanes = lanes_acc;
     *acc_T = T2;
     *acc_offs = offs_acc;

@@ -219,8 +219,19 @@ __device__ __forceinline__ uint32_t wave_atomic_inc(uint32_t* counter, uint32_t 
   uint32_t result = 0;
   unsigned long long pending = __ballot(active);
   const uint32_t lane = lane_id();
+  // Probe before aggregating (round 6): every aggregation round is an atomic whose return value the next round waits for -- with far
+  // more buckets than lanes (the usual window: 2^13 .. 2^17 buckets) three rounds served three lanes and cost three round trips in
+  // front of the per-lane atomics, four dependent latencies per window (k_scalar_digits: 0.18 ms for 2^15 scalars).  If neither the
+  // first nor the last pending lane shares its bucket with at least three others the wave goes straight to per-lane atomics: one
+  // latency.  Skewed digits (the top window, repeated scalars, zeros and ones) still aggregate.
+  int rounds = AGG_ROUNDS;
+  if (pending) {
+    const int first = __ffsll((long long)pending) - 1, last = 63 - __clzll((long long)pending);
+    const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, first), k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, last);
+    if (__popcll(__ballot(active && key == k1)) < 4 && __popcll(__ballot(active && key == k2)) < 4) rounds = 0;
+  }
 #pragma unroll 1
-  for (int r = 0; r < AGG_ROUNDS && pending; ++r) {
+  for (int r = 0; r < rounds && pending; ++r) {
     const int leader = __ffsll((long long)pending) - 1;
     const uint32_t lkey = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
     const bool mine = active && key == lkey && ((pending >> lane) & 1ull);
@@ -592,9 +603,6 @@ constexpr uint32_t ENTRY_EMPTY = 0xffffffffu;
 #ifndef MNT753_PAIR_WAVES
 #define MNT753_PAIR_WAVES 1
 #endif
-#ifndef MNT753_PAIR_DIET_SPLIT
-#define MNT753_PAIR_DIET_SPLIT 1
-#endif
 #ifndef MNT753_PAIR_DIET
 #define MNT753_PAIR_DIET 1
 #endif
@@ -672,13 +680,21 @@ constexpr uint32_t PAIR_LDS_BYTES = 4 * PAIR_LDS_WAVE_QUADS * 16;
 // (profiles/r05/level1_whole_row_pieces.txt) -- the number of DMA instructions is what the wave pays for, not their address arithmetic.)
 // portions the LDS-DMA of the next slot's image is issued in, one ahead of each of the first products of a slot: gathered rows of a
 // base field in four, of the lane-split fields in five, own planes in three (profiles/r03/ab_first_level_dma_portions.txt)
+// (round 6, with the shorter step loop of the base fields, same box, per 2^20-point G1 MSM -- profiles/r06/g1_dma_portions_ab.txt: the
+// regular later levels want TWO portions, 6.86 ms against 7.47 with three; the irregular ones three, 1.32 + 0.84 against 1.49 + 0.93
+// with two; reading the prefix product where it is multiplied instead of with the other operands: 6.94 / 1.39 + 0.92)
+#ifndef MNT753_PAIR_DMA_FIRST
+#define MNT753_PAIR_DMA_FIRST 4
+#endif
 #ifndef MNT753_PAIR_DMA_LATER
-#define MNT753_PAIR_DMA_LATER 3
+#define MNT753_PAIR_DMA_LATER 2
 #endif
-#ifndef MNT753_PAIR_PRE_TOP
-#define MNT753_PAIR_PRE_TOP 1      // development: 1 = the prefix product read with the other operands, 0 = where it is multiplied, 2 = 1 for the first level only
+#ifndef MNT753_PAIR_DMA_IRR
+#define MNT753_PAIR_DMA_IRR 3
 #endif
-constexpr uint32_t PAIR_DMA_STEPS_FIRST = 4, PAIR_DMA_STEPS_LATER = MNT753_PAIR_DMA_LATER;
+// (the lane-split fields keep three portions in their later levels: with two, MNT4753 G2 2^20 66.6-67.0 -> 68.9-69.6 ms, level 2 / 3
+// 10.59 -> 11.6 ms each; MNT6753 G2 2^15 unchanged -- profiles/r06/g2_dma_portions_ab.txt)
+constexpr uint32_t PAIR_DMA_STEPS_FIRST = MNT753_PAIR_DMA_FIRST, PAIR_DMA_STEPS_LATER = MNT753_PAIR_DMA_LATER, PAIR_DMA_STEPS_IRR = MNT753_PAIR_DMA_IRR;
 
 #ifdef MNT753_PAIR_TIMING
 // development: cycle totals of k_pair_level per wave (s_memtime): [0] forward, [1] inversion, [2] backward, [3] waves, [4..] ad hoc
@@ -828,8 +844,10 @@ __global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uin
   constexpr bool LAZY = has_lazy<F>::value;
   // round 6: the backward sweep keeps its operands where the multiplier reads them (below, "operands in place")
   constexpr bool DIET = LAZY && MNT753_PAIR_DIET;
-  // ... and the same loop shape for the lane-split fields (their fused multiplier, eager additions): MNT753_PAIR_DIET_SPLIT
-  constexpr bool DIET_S = !LAZY && F::LANES > 1 && MNT753_PAIR_DIET_SPLIT;
+  // (The same loop shape for the lane-split fields -- B <- A * B through their fused multiplier, one instance, lambda parked around the
+  // squaring -- was built and measured in round 6: MNT4753 G2 2^20 67.4-67.8 ms against 67.2-67.4 with the loop below, MNT6753 G2 2^15
+  // 8.5-8.7 against 8.65-8.8 (gpurun_out r6c, profiles/r06/g2_loop_shape_ab.txt): their products are 2187 / 2916 multiply-adds plus the
+  // partner exchange, the routing moves a smaller share, and the first level lost what the later ones gained.  Not kept.)
   extern __shared__ uint4 pair_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint4* img = pair_lds + (size_t)wave * PAIR_LDS_WAVE_QUADS;
@@ -1083,9 +1101,7 @@ __global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uin
     read_rows(n & 1u, std::false_type{}, img, f0, f1, x1, y1, x2, y2);
     if constexpr (IRR) { if (sw_cur >> 31) f1 = PF_EMPTY; }
     uint32_t kflag;
-    constexpr bool PRE_TOP = !DIET || MNT753_PAIR_PRE_TOP == 1 || (MNT753_PAIR_PRE_TOP == 2 && first);
-    if constexpr (PRE_TOP) kflag = fp_from_lds(pre, pre_img + lane, 64u);
-    else kflag = pre_img[6u * 64u + lane].w;
+    kflag = fp_from_lds(pre, pre_img + lane, 64u);
     const uint32_t kind = on ? kflag : (uint32_t)PK_EMPTY;
     const bool more = n + 1u < n_it;
     // blocked index (uint4 units) of the next slot's element: the per-lane part of the addresses of its planes and prefix product
@@ -1097,7 +1113,7 @@ __global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uin
     const bool flip = ((f0 ^ f1) & PF_NEG) != 0;
     uint32_t out_flag = PF_EMPTY;
     E num, ysave, yo;
-    if constexpr (!DIET && !DIET_S) {
+    if constexpr (!DIET) {
       ysave = y1;
       if (kind == PK_ADD) {
         out_flag = f1 & PF_NEG;
@@ -1139,7 +1155,7 @@ __global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uin
       // (first level, round 3: four portions for the base fields -- the last one then has two products to land in instead of one:
       // G1 2^20 25.04 / 24.93 -> 24.54 / 24.12 ms, three portions 24.45 / 24.35; the lane-split Fq2 wants five: 66.9 / 67.3 ms against
       // 68.5 / 68.5 with four; profiles/r03/ab_first_level_dma_portions.txt)
-      constexpr uint32_t DMA_STEPS = first ? (LN == 1 ? PAIR_DMA_STEPS_FIRST : 5u) : PAIR_DMA_STEPS_LATER;
+      constexpr uint32_t DMA_STEPS = first ? (LN == 1 ? PAIR_DMA_STEPS_FIRST : 5u) : (LN == 1 ? (IRR ? PAIR_DMA_STEPS_IRR : PAIR_DMA_STEPS_LATER) : 3u);
       constexpr uint32_t PER_STEP = (BWD_PIECES + DMA_STEPS - 1u) / DMA_STEPS;
       auto dma_step = [=](int step) __attribute__((always_inline)) {
         if (more && (uint32_t)step < DMA_STEPS) {
@@ -1197,16 +1213,20 @@ __global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uin
         }
       };
       if constexpr (DIET) {
-        // Operands in place (round 6).  The loop above routed two operands into the multiplier and one result out of it per product
-        // (~80 register moves each, and the nine live elements spilled into AGPRs and back).  Here the multiplier works on two
-        // blocks A, B with B <- A * B (fp_mul_s_ip), and every value is PRODUCED where its product reads it:
+        // Operands in place (round 6).  The loop below (round 5's, still the lane-split fields') routes two operands into the multiplier
+        // and one result out of it per product through a switch on either side: tools/isa_walk.py counts 1165 register moves per slot in
+        // it (v_mov and AGPR traffic: the compiler copies both operand blocks at every merge point) of 9632 VALU instructions.  Here the
+        // multiplier works on two blocks A, B with B <- A * B (fp_mul_s_ip), and every value is PRODUCED where its product reads it:
         //   0: A = inv, B = den = x2 - x1       B <- inv * den, kept as the next slot's inv (the one copy of the slot)
-        //   1: B = pre (out of the LDS image)   B <- inv * pre = 1 / den
+        //   1: B = pre                           B <- inv * pre = 1 / den
         //   2: A = num = y2 -+ y1               B <- num / den = lambda
-        //   3: S = B^2 (the squarer keeps B)    x2 <- norm(S - x1 - x2) = x3,  A = x1 - x3
-        //   4:                                   B <- lambda * (x1 - x3),  yo <- norm(B -+ y1) = y3'
-        // The prefix product leaves its image behind step 1, before the portion of the DMA that overwrites it (the last one).
-        static_assert((PRE_TOP || ROW_PIECES >= 2u * PER_STEP) && DMA_STEPS <= 4u, "a prefix product read at step 1 must not have its pieces in portions 0, 1; the loop has four iterations");
+        //   3: A <- B^2 (the squarer keeps B), x2 <- norm(A - x1 - x2) = x3, A <- x1 - x3;   B <- lambda * (x1 - x3)
+        //   behind the loop: yo <- norm(B -+ y1) = y3'
+        // 9029 instructions per slot by the walk; on the GPU 5.4 % fewer VALU instructions, level 1 11.2 -> 10.35 ms (profiles/r06/).
+        // Measured and NOT kept: a second switch behind the multiplier (first form: -1.8 % instructions only), the prefix product read
+        // from its image where it is multiplied (the ds_read queues behind the DMA's own LDS writes: irregular levels +6 %), results
+        // pinned to their operand's registers by tied asm operands (+1 move per limb), the same shape for the lane-split fields.
+        static_assert(DMA_STEPS <= 4u, "the loop has four iterations");
         E A = inv, B;
         if (kind == PK_ADD) {
           out_flag = f1 & PF_NEG;
@@ -1234,10 +1254,7 @@ __global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uin
           dma_step(step);
           switch (step) {
             case 0: break;
-            case 1:
-              inv = B;
-              if constexpr (PRE_TOP) B = pre; else (void)fp_from_lds(B, pre_img + lane, 64u);
-              break;
+            case 1: inv = B; B = pre; break;
             case 2: F::addsub_raw(A, y2, y1, !flip); break;    // y2 - y1  or  y2 + y1
             default:
               F::sqr_s_keep(A, B);
@@ -1252,48 +1269,6 @@ __global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uin
         F::addsub_raw(B, B, y1, !(kind == PK_ADD && flip));
         F::norm(B, B);
         yo = B;
-      } else if constexpr (DIET_S) {
-        // the lane-split fields in the same loop shape: B <- A * B through their fused multiplier (F::mul: one fp_mul2 / fp_mul3 per
-        // lane, partners' operands by ds_bpermute), eager additions, five DMA portions in the first level (the fifth between the
-        // squaring and the last product)
-        E A = inv, B, t;
-        if (kind == PK_ADD) {
-          out_flag = f1 & PF_NEG;
-          F::sub(B, x2, x1);
-        } else if (kind == PK_DBL) {
-          E a, nn;
-          fp_addsub<M>(B, y1, y2, flip);
-          F::mul(t, x1, x1);
-          F::add(nn, t, t); F::add(nn, nn, t);
-          C::coeff_a(a);
-          F::add(nn, nn, a);
-          fp_addsub<M>(y2, nn, y1, flip);         // y2 <- N +- y1, so that the y2 -+ y1 of step 2 is N again (mod p)
-          out_flag = f0 & PF_NEG;
-        } else {
-          F::one(B);
-        }
-        // ONE multiplier instance (2187 / 2916 multiply-adds: a second one would put the loop past the instruction cache): the squaring
-        // goes through it too, lambda parked around it
-        E lam;
-#pragma nounroll
-        for (int step = 0; step < 5; ++step) {
-          dma_step(step);
-          switch (step) {
-            case 0: break;
-            case 1: inv = B; B = pre; break;
-            case 2: fp_addsub<M>(A, y2, y1, !flip); break;
-            case 3: lam = B; A = B; break;
-            default:
-              F::sub(t, B, x1);
-              F::sub(x2, t, x2);
-              F::sub(A, x1, x2);
-              B = lam;
-              break;
-          }
-          F::mul(t, A, B);
-          B = t;
-        }
-        fp_addsub<M>(yo, B, y1, !(kind == PK_ADD && flip));
       } else {
 #pragma nounroll
         for (int step = 0; step < 5; ++step) {
@@ -1349,7 +1324,7 @@ __global__ void __launch_bounds__(256, MNT753_PAIR_WAVES) k_pair_level(const uin
     if (kind == PK_SINGLE) {                    // odd leftover: copy, the sign travels in the flag
       out_flag = f0 & PF_NEG;
       x2 = x1;
-      if constexpr (DIET || DIET_S) yo = y1; else yo = ysave;
+      if constexpr (DIET) yo = y1; else yo = ysave;
     }
     {
       if (kind == PK_CANCEL) {                  // P + (-P): emit D, remember to take it out of the bucket again

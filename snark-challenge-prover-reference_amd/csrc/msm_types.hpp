@@ -40,12 +40,13 @@ struct mnt753_bases {
   uint32_t *d_part_a = nullptr, *d_part_b = nullptr, *d_tmp = nullptr;
   // pairing levels (batched affine additions ahead of the accumulate): grow-only buffers
   uint32_t *d_pair_ws = nullptr, *d_fix = nullptr, *d_gen = nullptr;   // prefix products, cancellation counts per bucket, the stand-in point D
-  uint32_t *d_pairpts[2] = {nullptr, nullptr}, *d_sorted2 = nullptr;    // rows of the levels (ping-pong), entry list of the last level
+  uint32_t *d_pairpts[2] = {nullptr, nullptr}, *d_sorted2 = nullptr;    // rows of the levels (ping-pong), entry list of the last level: the DEVICE's pooled buffers (PairPool, msm_host.hpp), bound per MSM
   uint32_t *d_irr_offs[2] = {nullptr, nullptr}, *d_irr_src = nullptr, *d_irr_blocks = nullptr;   // irregular levels: bucket offsets (ping-pong), source words, block sums
   size_t pair_cap = 0;   // level-1 slots the pairing buffers hold
   size_t pair_buckets = 0;   // buckets d_fix holds
   size_t sorted_cap = 0;     // entries d_sorted holds (padded layout: W*n + n_buckets*(2^levels - 1))
   int no_pair = 0;       // the pairing workspace could not be allocated: this set runs the plain accumulate
+  int registered = 0;    // counted in its device's PairPool (mnt753_bases_create got as far as registering the set)
   uint32_t* d_wire_out = nullptr;
   uint64_t* h_wire_out = nullptr;   // pinned
   uint64_t* d_scalars_stage = nullptr;
@@ -57,3 +58,22 @@ struct mnt753_bases {
   const mnt753_bases* after_owner = nullptr;   // the set that owns after_ev: mnt753_bases_free of that set clears both
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
+
+namespace mnt753 {
+// The big buffers of the batched-affine levels -- the rows of the levels (ping-pong), the entry list of the last level, one prefix
+// product per slot: 9.4 GB of a 2^20-point G1 set's 10.5 GB of workspace, 28 GB for H | L | B1, 15.6 GB for the G2 set -- are used
+// between the sort and the accumulate kernel only, and the level kernels of two MSMs never overlap anyway (each fills the chip).
+// Round 6: ONE set of them per DEVICE, sized for the largest request and handed from MSM to MSM by an event behind the accumulate
+// kernel (what mnt753_msm_order_after does for the small sets): 53 -> 28 GB per MNT4753 parameter set.  Sorts, edge merges and bucket
+// reductions keep their own buffers and still run under another MSM's levels.
+struct PairPool {
+  void* buf[4] = {nullptr, nullptr, nullptr, nullptr};   // rows of levels 1, 3, 5 | rows of levels 2, 4, 6 | entry list of the last level | prefix products
+  size_t cap[4] = {0, 0, 0, 0};
+  hipEvent_t last_acc = nullptr;   // behind the accumulate kernel of the MSM that used the buffers last
+  bool used = false;
+  int refs = 0;                    // base sets alive on the device
+};
+constexpr int PAIR_POOL_DEVICES = 32;
+extern PairPool g_pair_pool[PAIR_POOL_DEVICES];
+inline PairPool& pair_pool_of(const mnt753_bases* b) { return g_pair_pool[(unsigned)b->device % PAIR_POOL_DEVICES]; }
+}  // namespace mnt753

@@ -643,19 +643,19 @@ template <int CURVE> void HIP_B::init_public_params() {
       }
   } else check(mnt753_init(0), "mnt753_init");
   // Known answers of THIS build, once per process, before anything is proved with it (mnt753_self_test, include/mnt753_hip.h; the
-  // reference's check of the same purpose: libsnark/main.cpp:295-343).  ~20 ms inside the parameter-load phase, outside the timing
+  // reference's check of the same purpose: libsnark/main.cpp:295-343).  ~75 ms for this class's curve, inside the parameter-load phase, outside the timing
   // window (main.cpp:201-203).  A mismatch is fatal: a prover must not write proofs with arithmetic that fails its known answers.
-  static bool self_tested = false;
-  if (!self_tested) {
+  static bool self_tested[2] = {false, false};
+  if (!self_tested[CURVE]) {
     int level = 1;
     if (const char* e = getenv("MNT753_SELFTEST")) level = atoi(e);
     if (level > 0) {
       const auto t0 = std::chrono::steady_clock::now();
-      check(mnt753_self_test(level > 2 ? 2 : level), "mnt753_self_test");
+      check(mnt753_self_test_curve(CURVE, level > 2 ? 2 : level), "mnt753_self_test");
       if (trace_load_on()) fprintf(stderr, "mnt753: load params: %-46s %7.3f s\n", "known-answer self-test of this build",
                                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
-    self_tested = true;
+    self_tested[CURVE] = true;
   }
 }
 
@@ -1112,6 +1112,8 @@ template <int CURVE> static void warm_up(typename mnt753_hip_impl<CURVE>::groth1
     for (auto& set : pm->sets) check(mnt753_msm_finish(set->h, sink), "mnt753_msm_finish(warm-up)");
 }
 template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const char* path) {
+  size_t mem_free0 = 0, mem_total = 0;
+  if (trace_load_on()) (void)mnt753_dev_mem_info(&mem_free0, &mem_total);
   // a one-proof process builds its base sets without window tables (include/mnt753_hip.h, mnt753_msm_set_window_table)
   struct TableMode {
     int old;
@@ -1127,6 +1129,11 @@ template <int CURVE> typename HIP_B::groth16_params* HIP_B::read_params(const ch
   lt.lap("evaluation domain(s): twiddle and coset tables");
   warm_up<CURVE>(p);
   lt.lap("warm-up MSM per base set");
+  if (trace_load_on()) {
+    size_t mem_free1 = 0;
+    if (mnt753_dev_mem_info(&mem_free1, &mem_total) == 0 && mem_free0 >= mem_free1)
+      fprintf(stderr, "mnt753: load params: device memory of this parameter set (device 0): %.1f GB (tables, workspaces, pooled level buffers)\n", (mem_free0 - mem_free1) / 1e9);
+  }
   // the buffers of one proof, allocated now and parked in the cache: w, ca, cb, cc, coefficients_for_H, the scalars of groth16_C, and
   // with several devices each device's range of w, its vector of compute_H and the staging of the transformed cb / cc on device 0
   {

@@ -150,7 +150,7 @@ def test_self_test_is_run_once_and_is_fatal(san, tmp_path):
         env = dict(os.environ, MNT753_STUB_LOG="1", ASAN_OPTIONS="detect_leaks=0", **extra)
         return subprocess.run([san["asan"], "MNT4753", "compute", params, inp, out, "--repeat", "2"], capture_output=True, text=True, env=env, timeout=600)
     r = go({})
-    assert r.returncode == 0 and r.stderr.count("stub: self-test level 1") == 1, r.stderr[-800:]
+    assert r.returncode == 0 and r.stderr.count("stub: self-test level 1 curve 0") == 1, r.stderr[-800:]
     r = go({"MNT753_SELFTEST": "0"})
     assert r.returncode == 0 and "stub: self-test" not in r.stderr
     r = go({"MNT753_STUB_SELFTEST_FAILS": "1"})

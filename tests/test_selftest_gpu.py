@@ -27,6 +27,8 @@ def run_level(level, corrupt=None):
 @pytest.mark.parametrize("level", [0, 1, 2])
 def test_self_test_passes_on_this_build(gpu, level):
     gpu.api.self_test(level)
+    for curve in (0, 1):
+        gpu.api.self_test(level, curve=curve)
 
 
 @pytest.mark.parametrize("level,k", [(1, 0), (1, 7), (1, 8), (1, 9), (1, 11), (1, 12), (1, 13), (1, 16), (1, 17), (2, 10), (2, 11), (2, 25)])
@@ -50,10 +52,11 @@ def test_prover_runs_it_and_refuses_to_prove_behind_a_failure(gpu, tmp_path):
     assert r.returncode == 0 and "known-answer self-test of this build" in r.stderr, r.stderr[-600:]
     assert open(out, "rb").read() == open(expected, "rb").read()
     os.remove(out)
-    r = subprocess.run([EXE, "MNT6753", "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_SELFTEST_CORRUPT="9"))
-    assert r.returncode == 1 and "self-test check 9 failed" in r.stderr, r.stderr[-600:]
+    # the wrapper tests ITS curve (mnt753_self_test_curve): 4 host checks, then G1 plain / levels (4, 5), G2 (6, 7), compute_H (8)
+    r = subprocess.run([EXE, "MNT6753", "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_SELFTEST_CORRUPT="7"))
+    assert r.returncode == 1 and "self-test check 7 failed" in r.stderr and "MNT6753 G2" in r.stderr, r.stderr[-600:]
     assert not os.path.exists(out), "a prover whose self-test failed must not write a proof"
-    r = subprocess.run([EXE, "MNT6753", "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_SELFTEST_CORRUPT="9", MNT753_SELFTEST="0"))
+    r = subprocess.run([EXE, "MNT6753", "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_SELFTEST_CORRUPT="7", MNT753_SELFTEST="0"))
     assert r.returncode == 0      # switched off: nothing runs, nothing can fail
     r = subprocess.run([EXE, "MNT4753", "self-test"], capture_output=True, text=True)
     assert r.returncode == 0 and "all known answers" in r.stdout, r.stderr[-600:]

@@ -36,6 +36,12 @@ M=$R/snark-challenge-prover-reference_amd/main_hip
 { echo "== main_hip MNT6753 d = 2^15 - 1"; $M MNT6753 compute $K/p6 $K/i6 $K/o6 --repeat 3; sha256sum $K/o6;
   echo "== CPU: the reference prover (oracle/_ref/main, $(nproc) hardware threads)"; if [ -x oracle/_ref/main ]; then oracle/_ref/main MNT6753 compute $K/p6 $K/i6 $K/o6ref 2>&1 | grep -i "total time"; sha256sum $K/o6ref; fi;
   echo "== CPU: the oracle restatement (oracle_main)"; oracle/oracle_main MNT6753 compute $K/p6 $K/i6 $K/o6or; sha256sum $K/o6or; } > $O/full_prove_MNT6753_2p15.log 2>&1
+# round 6: the one-shot prover (one job: no window tables, no level buffers, no warm-up; host/main.cpp) -- the wall clock of the whole
+# process, three times with pauses, against --tables; and the product's self-test per curve
+wall() { t0=$(date +%s.%N); "$@" > $K/stdout.txt 2> $K/stderr.txt; rc=$?; t1=$(date +%s.%N); echo "rc $rc wall $(python3 -c "print(round($t1 - $t0, 3))") s | $(grep -E 'load params:|Total time from' $K/stdout.txt | tr '\n' ' ')"; }
+{ for k in 1 2 3; do sleep 20; echo -n "one-shot : "; wall $M MNT4753 compute $K/p4 $K/i4 $K/o1; sleep 20; echo -n "--tables : "; wall $M MNT4753 compute $K/p4 $K/i4 $K/o2 --tables; cmp $K/o1 $K/o2 && echo "same bytes"; done;
+  sleep 20; MNT753_TRACE_LOAD=1 $M MNT4753 compute $K/p4 $K/i4 $K/o1 2>&1 | grep -E "load params|one-shot|Total"; sha256sum $K/o1;
+  echo "== MNT6753 2^15, one-shot"; sleep 5; wall $M MNT6753 compute $K/p6 $K/i6 $K/o61; sha256sum $K/o61; $M MNT4753 self-test; } > $O/one_shot_wall.txt 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/kt_prove -o prove -- $M MNT4753 compute $K/p4 $K/i4 $K/o4 --repeat 2 > $O/prove_under_rocprof.log 2>&1
 cd $R; rm -rf $K

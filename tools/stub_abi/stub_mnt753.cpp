@@ -125,6 +125,8 @@ int mnt753_msm(mnt753_bases* b, size_t off, const uint64_t* sc, int od, size_t n
   return mnt753_msm_finish(b, out);
 }
 int mnt753_msm_set_window_bits(int) { return 0; }
+int mnt753_dev_mem_info(size_t* f, size_t* t) { if (f) *f = (size_t)200 << 30; if (t) *t = (size_t)288 << 30; return 0; }
+int mnt753_self_test_curve(int curve, int level) { if (getenv("MNT753_STUB_LOG")) fprintf(stderr, "stub: self-test level %d curve %d\n", level, curve); const char* e = getenv("MNT753_STUB_SELFTEST_FAILS"); return e && atoi(e) ? fail(MNT753_ESELFTEST, "stub: self-test check 3 failed (as asked)") : 0; }
 int mnt753_self_test(int level) { if (getenv("MNT753_STUB_LOG")) fprintf(stderr, "stub: self-test level %d\n", level); const char* e = getenv("MNT753_STUB_SELFTEST_FAILS"); return e && atoi(e) ? fail(MNT753_ESELFTEST, "stub: self-test check 3 failed (as asked)") : 0; }
 int mnt753_msm_set_window_table(int mode) { static int m = 1; const int old = m; m = mode != 0; if (getenv("MNT753_STUB_LOG")) fprintf(stderr, "stub: window table mode %d\n", m); return old; }
 int mnt753_msm_order_after(mnt753_bases* b, const mnt753_bases* first) { return (b && first && b != first) ? 0 : 22; }
