@@ -390,6 +390,9 @@ int ensure_pair_ws(mnt753_bases* b, const MsmPlan& p, size_t n) {
     const size_t slack = 4 * 64 * 7 * 16 * 2;
     // the device's pooled buffers: grown to what THIS set needs (bytes: the sets of a device differ in row width), then bound
     {
+      // (one set per device for EVERY base set: letting the small sets keep buffers of their own, so that A's MSM still interleaves with
+      // C's, was measured -- 0.1547-0.1566 s per prove against 0.1545-0.1560 pooled and 0.1543-0.1584 unpooled, 100 / 90 / 120 GB:
+      // profiles/r06/level_buffers_pooling_ab.txt -- and bought nothing)
       PairPool& pool = pair_pool_of(b);
       const size_t need[4] = {sizeof(uint32_t) * aff_words<V>() * capA + slack * V::F::DEG,                      // levels 1, 3, 5
                               // (an irregular level writes at most half its input plus one slot per bucket: the buckets' worth of room covers it at any depth)

@@ -64,7 +64,8 @@ namespace mnt753 {
 // product per slot: 9.4 GB of a 2^20-point G1 set's 10.5 GB of workspace, 28 GB for H | L | B1, 15.6 GB for the G2 set -- are used
 // between the sort and the accumulate kernel only, and the level kernels of two MSMs never overlap anyway (each fills the chip).
 // Round 6: ONE set of them per DEVICE, sized for the largest request and handed from MSM to MSM by an event behind the accumulate
-// kernel (what mnt753_msm_order_after does for the small sets): 53 -> 28 GB per MNT4753 parameter set.  Sorts, edge merges and bucket
+// kernel (what mnt753_msm_order_after does for the small sets): 53 -> 28 GB per MNT4753 parameter set, 120 -> 90 GB in all, the
+// resident prove unchanged (0.1545-0.1560 s against 0.1543-0.1584, profiles/r06/level_buffers_pooling_ab.txt).  Sorts, edge merges and bucket
 // reductions keep their own buffers and still run under another MSM's levels.
 struct PairPool {
   void* buf[4] = {nullptr, nullptr, nullptr, nullptr};   // rows of levels 1, 3, 5 | rows of levels 2, 4, 6 | entry list of the last level | prefix products
