@@ -112,6 +112,11 @@ def test_reference_driver_unchanged(gpu, curve, tmp_path):
     # ... and its three multiexps over B1 / L / H plus G1_scale and two G1_add ran as ONE MSM over the concatenated set (LazyPoint in
     # host/prover_hip_functions.cpp), without a line of the driver knowing
     assert "one MSM over H | L | B1" in r.stderr
+    # ... and, told so through the environment, it proves as the one-shot process it is (no window tables, no warm-up: INTEGRATION.md 1)
+    os.remove(out)
+    r = subprocess.run([exe, NAME[curve], "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_ONE_SHOT="1", MNT753_TRACE_LOAD="1"))
+    assert r.returncode == 0, r.stderr
+    assert "one-shot prover: no window tables" in r.stderr and filecmp.cmp(out, expected, shallow=False)
     r = subprocess.run([exe, NAME[curve], "compute", params, inp, out], capture_output=True, text=True, env=dict(os.environ, MNT753_TRACE="1", MNT753_FUSED_C="0"))
     assert r.returncode == 0, r.stderr
     assert filecmp.cmp(out, expected, shallow=False) and "one MSM" not in r.stderr
