@@ -51,6 +51,10 @@ int pick_window_bits(size_t n) {
 // merge, one general addition per level, becomes the longest phase of a small MSM.  profiles/r03/window_width_sweep.txt, G1:
 //   2^20 points 25.0 / 24.3 / 25.0 / 26.2 ms at c = 18 / 19 / 20 / 21;  3 * 2^20: 66.0 / 64.1 / 62.3 / 62.0;  2^17: 5.3 ms at 18 against 6.2
 //   at 17;  MNT6753 2^15: 2.6 ms at 18 against 3.7 at 16.   Fq2 G2 2^20: 66.9 / 65.6 / 67.3 / 71.6 ms.
+// Round 6, behind the cheaper levels (profiles/r06/window_width_sweep.txt, MNT753_MSM_TABLE_BITS): the same widths win -- 2^20 G1
+// 23.2 / 22.7 / 23.5 / 24.6 ms at 18 / 19 / 20 / 21, H | L | B1 57.7 / 57.9 / 63.9 at 20 / 21 / 22, Fq2 G2 68.5 / 67.1 / 68.8 at 18 / 19 / 20.  A
+// level's time follows its padded slot pairs (0.49 ns each), and the padding of every bucket's last group of eight grows with the
+// bucket count as fast as the entries shrink (kernels_by_window_width.txt).
 int pick_precomp_bits(size_t n, double bucket_weight = 8.0, int min_c = 2) {
   int best = min_c; double best_cost = 1e300;
   for (int c = min_c; c <= 22; ++c) {
@@ -231,6 +235,7 @@ int bases_create_t(mnt753_bases* b, const uint64_t* affine, int on_device, size_
     if (C::F::DEG == 1) pc = pick_precomp_bits(n, 8.0, n <= 4096 ? 14 : 18);
     else if (C::F::DEG == 2) pc = pick_precomp_bits(n, 8.0, n >= ((size_t)1 << 16) ? 18 : 2);
     else pc = n <= ((size_t)1 << 15) ? 14 : pick_precomp_bits(n, 8.0, 2);
+    if (const char* e = getenv("MNT753_MSM_TABLE_BITS")) { int v = atoi(e); if (v >= 8 && v <= 22) pc = v; }   // tools/experiments/window_sweep.sh
     pW = (754 + pc - 1) / pc;
     if ((uint64_t)pW * n >= 0x7fffffffull) { want_table = false; pc = 0; pW = 1; }   // row index must fit 31 bits
   }
