@@ -160,14 +160,16 @@ void free_ws(mnt753_bases* b) {
   b->sorted_cap = 0;
 }
 
-// Sort stage from 2^22 entries on: the hand-written two-level counting sort of msm_sort.hip instead of the histogram-atomic counting
-// sort (below that its handful of launches cost more than the atomics it saves).  MNT753_MSM_SORT=atomic / part overrides (the tests
-// run both stages on small and large inputs).  (rocPRIM's radix sort, the stage of round 2 -- 1.33 ms against 0.92 -- left the product
-// in round 5.)
+// Sort stage from 2^20 entries on: the hand-written two-level counting sort of msm_sort.hip instead of the histogram-atomic counting
+// sort (below that its handful of launches cost more than the atomics it saves: profiles/r06/sort_stage_by_width.txt -- 2^14 points
+// 0.088 ms atomic / 0.111 partitioned, 2^15 0.134 / 0.106, 98 302 points 0.317 / 0.132, 2^16 0.231 / 0.112; the threshold was 2^22 until
+// the partition passes took the window width as a template parameter).  MNT753_MSM_SORT=atomic / part overrides (the tests run both
+// stages on small and large inputs), =generic also keeps the partition passes on the kernels that read the width at run time.
+// (rocPRIM's radix sort, the stage of round 2 -- 1.33 ms against 0.92 -- left the product in round 5.)
 enum SortMode { SORT_ATOMIC = 0, SORT_PART = 2 };
 inline SortMode sort_mode(uint64_t entries) {
   if (const char* e = getenv("MNT753_MSM_SORT")) return !strcmp(e, "atomic") ? SORT_ATOMIC : SORT_PART;
-  return entries >= ((uint64_t)1 << 22) ? SORT_PART : SORT_ATOMIC;
+  return entries >= ((uint64_t)1 << 20) ? SORT_PART : SORT_ATOMIC;
 }
 template <class C>
 int ensure_ws(mnt753_bases* b, size_t n, const MsmPlan& p) {

@@ -73,6 +73,22 @@ __device__ __forceinline__ uint32_t block256_exclusive_scan(uint32_t v, uint32_t
   }
   return scratch[t] - v;
 }
+// the same over the four waves of a block with wave shuffles: one barrier instead of sixteen (scratch: 4 words); *total = the block's sum
+__device__ __forceinline__ uint32_t block256_exclusive_scan_shfl(uint32_t v, uint32_t* scratch, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) scratch[wid] = x;
+  __syncthreads();
+  const uint32_t s0 = scratch[0], s1 = scratch[1], s2 = scratch[2], s3 = scratch[3];
+  *total = s0 + s1 + s2 + s3;
+  const uint32_t before = wid == 0 ? 0u : wid == 1 ? s0 : wid == 2 ? s0 + s1 : s0 + s1 + s2;
+  return before + x - v;
+}
 // dynamic LDS of the placing pass: scalar words, partition histogram / local starts / global bases, scan scratch, the block's
 // (key, value) pairs (W per scalar); of the counting pass: scalar words and the histogram
 inline size_t part_place_lds(uint32_t n_parts, int W) { return sizeof(uint32_t) * (24u * 256u + 3u * (size_t)n_parts + 256u + 2u * 256u * (size_t)W); }
@@ -137,6 +153,100 @@ __global__ void __launch_bounds__(256) k_part_pass(const uint32_t* __restrict__ 
       const uint32_t pos = base[p] + (j - lstart[p]);
       keys[pos] = key;
       vals[pos] = st_v[j];
+    }
+  }
+}
+// ---- the same pass with the window width a template parameter (round 6) ----------------------------------------------------------
+// k_part_pass reads its digits out of LDS (lds_bits: the position is a run-time value, registers cannot be indexed by one) and
+// extracts every digit twice, once to count and once to place: ~25 of its ~60 instructions per digit, and with the scalar words
+// (24.5 KB) and a (key, value) pair per digit (82 KB at W = 40) one workgroup per CU -- one wave per SIMD, every LDS atomic and
+// global access paid in full latency: 0.41 ms for 100 MB read + 335 MB written (1 TB/s) at 2^20 scalars.  With C known at compile
+// time the loop over the windows unrolls: the scalar stays in 24 registers, a digit is two shifts and a mask and is kept (W
+// registers) from the counting loop to the placing loop, and the staged pair shrinks to one word -- low 10 bits of the key,
+// window, owner thread, sign -- plus a 16-bit partition number: 65 KB at W = 40, two workgroups per CU.
+template <int C>
+__device__ __forceinline__ uint32_t reg_bits(const uint32_t (&s)[24], int pos, int nbits) {   // pos, nbits: constants after unrolling
+  if (pos >= 768) return 0u;
+  const int wi = pos >> 5, sh = pos & 31;
+  uint32_t v = s[wi] >> sh;
+  if (sh + nbits > 32 && wi + 1 < 24) v |= s[wi + 1] << (32 - sh);
+  return v & ((1u << nbits) - 1u);
+}
+inline size_t part_place_lds_c(uint32_t n_parts, int W) { return sizeof(uint32_t) * (3u * (size_t)n_parts + 256u + 256u * (size_t)W) + sizeof(uint16_t) * 256u * (size_t)W; }
+template <int FRM, int C, bool PLACE>
+__global__ void __launch_bounds__(256) k_part_pass_c(const uint32_t* __restrict__ scal_wire, const uint8_t* __restrict__ inf, size_t n,
+                                                    uint32_t hist_stride, uint32_t entry_stride, uint32_t entry_base, uint32_t n_parts,
+                                                    uint32_t* __restrict__ part_total, uint32_t* __restrict__ part_cursor,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  constexpr int W = (754 + C - 1) / C;
+  static_assert(W < 64, "the staged word holds the window in six bits");
+  extern __shared__ uint32_t part_lds[];
+  uint32_t* hist = part_lds;                     // [n_parts]
+  const int tid = threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + tid;
+  uint32_t s[24];
+  {
+    uint32_t w[24];
+    if (i < n) {
+      load_wire24(w, scal_wire + i * 24);
+      fp_wire_to_integer<FRM>(s, w);
+    }
+    if (i >= n || inf[i]) {
+#pragma unroll
+      for (int j = 0; j < 24; ++j) s[j] = 0;
+    }
+  }
+  for (uint32_t p = tid; p < n_parts; p += 256) hist[p] = 0;
+  __syncthreads();
+  int32_t d[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    const uint32_t win = reg_bits<C>(s, w * C, C);
+    const uint32_t blo = w ? reg_bits<C>(s, w * C - 1, 1) : 0u;
+    const uint32_t top = (win >> (C - 1)) & 1u;
+    d[w] = (int32_t)win + (int32_t)blo - (int32_t)(top << C);
+    if (d[w]) atomicAdd(&hist[((uint32_t)w * hist_stride + (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1u) >> PART_BITS], 1u);
+  }
+  __syncthreads();
+  if constexpr (!PLACE) {
+    for (uint32_t p = tid; p < n_parts; p += 256) { const uint32_t cnt = hist[p]; if (cnt) atomicAdd(&part_total[p], cnt); }
+  } else {
+    uint32_t* lstart = hist + n_parts;           // [n_parts] start of the partition inside the block's ordered list
+    uint32_t* base = lstart + n_parts;           // [n_parts] start of the block's range inside the partition (global)
+    uint32_t* scratch = base + n_parts;          // [256]
+    uint32_t* st = scratch + 256;                // [256 * W] key & 1023 | window << 10 | owner thread << 16 | sign << 24
+    uint16_t* st_p = reinterpret_cast<uint16_t*>(st + 256u * (uint32_t)W);   // [256 * W] partition
+    const uint32_t per = (n_parts + 255u) / 256u;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t p = tid * per + k; if (p < n_parts) mine += hist[p]; }
+    uint32_t block_total;
+    uint32_t run = block256_exclusive_scan_shfl(mine, scratch, &block_total);
+    for (uint32_t k = 0; k < per; ++k) {
+      const uint32_t p = tid * per + k;
+      if (p < n_parts) {
+        const uint32_t cnt = hist[p];
+        lstart[p] = run; run += cnt;
+        base[p] = cnt ? atomicAdd(&part_cursor[p], cnt) : 0u;
+        hist[p] = 0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      if (!d[w]) continue;
+      const uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1u;
+      const uint32_t p = key >> PART_BITS;
+      const uint32_t j = lstart[p] + atomicAdd(&hist[p], 1u);
+      st[j] = (key & (PART_BUCKETS - 1u)) | ((uint32_t)w << 10) | ((uint32_t)tid << 16) | (d[w] < 0 ? 1u << 24 : 0u);
+      st_p[j] = (uint16_t)p;
+    }
+    __syncthreads();
+    const uint32_t i0 = entry_base + blockIdx.x * 256u;
+    for (uint32_t j = tid; j < block_total; j += 256) {
+      const uint32_t v = st[j], p = st_p[j];
+      const uint32_t pos = base[p] + (j - lstart[p]);
+      keys[pos] = (p << PART_BITS) | (v & (PART_BUCKETS - 1u));
+      vals[pos] = (((v >> 10) & 63u) * entry_stride + i0 + ((v >> 16) & 255u)) | ((v >> 24) << 31);
     }
   }
 }
@@ -232,22 +342,36 @@ __global__ void __launch_bounds__(1024) k_bucket_place_staged(const uint32_t* __
     const uint32_t s = max(ps, lo), e = min(pe, hi);
     if (s >= e) continue;
     const uint32_t b0 = p << PART_BITS;
+    // this thread's (at most PLACE_CHUNK / 1024 = 16) pairs, all loads in flight at once and each pair read once (round 6; before: keys
+    // read in the counting loop and again, with the values, in the ranking loop -- three exposed latencies per segment instead of one)
+    uint32_t kb[PLACE_CHUNK / 1024], vv[PLACE_CHUNK / 1024];
+#pragma unroll
+    for (uint32_t q = 0; q < PLACE_CHUNK / 1024; ++q) {
+      const uint32_t k = s + t + q * 1024u;
+      const bool in = k < e;
+      kb[q] = in ? keys[k] - b0 : 0xffffffffu;
+      vv[q] = in ? vals[k] : 0u;
+    }
     cnt[t] = 0;
     __syncthreads();
-    for (uint32_t k = s + t; k < e; k += 1024) atomicAdd(&cnt[keys[k] - b0], 1u);
+#pragma unroll
+    for (uint32_t q = 0; q < PLACE_CHUNK / 1024; ++q) if (kb[q] != 0xffffffffu) atomicAdd(&cnt[kb[q]], 1u);
     __syncthreads();
     const uint32_t v = cnt[t];
+    // the bucket's range is reserved (a global atomic whose value is needed) while the scan runs
+    const uint32_t reserved = v ? (offsets[b0 + t] << shift) + atomicAdd(&placed[b0 + t], v) : 0u;
     uint32_t seg_total;
     const uint32_t ex = block_exclusive_scan(v, &seg_total);   // (1024 threads; ends with a barrier)
     lstart[t] = ex;
-    base[t] = v ? (offsets[b0 + t] << shift) + atomicAdd(&placed[b0 + t], v) : 0u;
+    base[t] = reserved;
     cnt[t] = 0;
     __syncthreads();
-    for (uint32_t k = s + t; k < e; k += 1024) {
-      const uint32_t kb = keys[k] - b0;
-      const uint32_t j = lstart[kb] + atomicAdd(&cnt[kb], 1u);
-      st_v[j] = vals[k];
-      st_b[j] = (uint16_t)kb;
+#pragma unroll
+    for (uint32_t q = 0; q < PLACE_CHUNK / 1024; ++q) {
+      if (kb[q] == 0xffffffffu) continue;
+      const uint32_t j = lstart[kb[q]] + atomicAdd(&cnt[kb[q]], 1u);
+      st_v[j] = vv[q];
+      st_b[j] = (uint16_t)kb[q];
     }
     __syncthreads();
     for (uint32_t j = t; j < e - s; j += 1024) {
@@ -281,18 +405,42 @@ int msm_sort_partition(int frm, const uint32_t* d_scal, const uint8_t* d_inf, si
   const uint32_t pshift = (uint32_t)p.pair_levels;
   HIP_TRY(hipMemsetAsync(part_total, 0, sizeof(uint32_t) * (PART_MAX + 1), st));
   HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (size_t)p.n_buckets, st));
-  const size_t lds_place = part_place_lds(n_parts, p.W), lds_count = sizeof(uint32_t) * (24u * 256u + (size_t)n_parts);
-  if (lds_place > PART_LDS_LIMIT) return set_error(MNT753_EINVAL, "msm_sort_partition: plan does not fit the LDS staging");
-  // the placing passes stage their pairs in up to 160 KB of dynamic LDS: the opt-in is per kernel AND device, the call costs
-  // microseconds, so it is simply repeated on whatever device this MSM runs on
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(frm == MOD_A ? (const void*)&k_part_pass<MOD_A, true> : (const void*)&k_part_pass<MOD_B, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT));
+  // window width known to a template (14 .. 22: every width pick_precomp_bits / pick_window_bits hands out for sets this large):
+  // digits from registers, one staged word per entry (k_part_pass_c); any other width, or MNT753_MSM_SORT=generic: k_part_pass
+  const char* sort_env = getenv("MNT753_MSM_SORT");
+  const bool generic_only = sort_env && !strcmp(sort_env, "generic");
+  const bool by_width = !generic_only && p.c >= 14 && p.c <= 22 && part_place_lds_c(n_parts, p.W) <= PART_LDS_LIMIT;
+  if (by_width) {
+    const size_t lds_place = part_place_lds_c(n_parts, p.W), lds_count = sizeof(uint32_t) * (size_t)n_parts;
+#define MNT753_PART_PASS_C(FRM, C)                                                                                                              \
+  {                                                                                                                                             \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_pass_c<FRM, C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT)); \
+    hipLaunchKernelGGL((k_part_pass_c<FRM, C, false>), dim3(gb), dim3(256), lds_count, st, d_scal, d_inf, n, hs, entry_stride, entry_base, n_parts, part_total, part_cursor, keys_out, vals_out); \
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, part_cursor, n_parts);                                   \
+    hipLaunchKernelGGL((k_part_pass_c<FRM, C, true>), dim3(gb), dim3(256), lds_place, st, d_scal, d_inf, n, hs, entry_stride, entry_base, n_parts, part_total, part_cursor, keys_out, vals_out); \
+  }
+#define MNT753_PART_PASS_W(C) case C: if (frm == MOD_A) MNT753_PART_PASS_C(MOD_A, C) else MNT753_PART_PASS_C(MOD_B, C) break;
+    switch (p.c) {
+      MNT753_PART_PASS_W(14) MNT753_PART_PASS_W(15) MNT753_PART_PASS_W(16) MNT753_PART_PASS_W(17) MNT753_PART_PASS_W(18)
+      MNT753_PART_PASS_W(19) MNT753_PART_PASS_W(20) MNT753_PART_PASS_W(21) MNT753_PART_PASS_W(22)
+      default: return set_error(MNT753_EINVAL, "msm_sort_partition: window width outside the instantiated range");
+    }
+#undef MNT753_PART_PASS_W
+#undef MNT753_PART_PASS_C
+  } else {
+    const size_t lds_place = part_place_lds(n_parts, p.W), lds_count = sizeof(uint32_t) * (24u * 256u + (size_t)n_parts);
+    if (lds_place > PART_LDS_LIMIT) return set_error(MNT753_EINVAL, "msm_sort_partition: plan does not fit the LDS staging");
+    // the placing passes stage their pairs in up to 160 KB of dynamic LDS: the opt-in is per kernel AND device, the call costs
+    // microseconds, so it is simply repeated on whatever device this MSM runs on
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(frm == MOD_A ? (const void*)&k_part_pass<MOD_A, true> : (const void*)&k_part_pass<MOD_B, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT));
 #define MNT753_PART_PASS(FRM, PLACE) hipLaunchKernelGGL((k_part_pass<FRM, PLACE>), dim3(gb), dim3(256), (PLACE) ? lds_place : lds_count, st, d_scal, d_inf, n, p.c, p.W, hs, entry_stride, entry_base, \
                                                         n_parts, part_total, part_cursor, keys_out, vals_out)
-  if (frm == MOD_A) MNT753_PART_PASS(MOD_A, false); else MNT753_PART_PASS(MOD_B, false);
-  hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, part_cursor, n_parts);
-  if (frm == MOD_A) MNT753_PART_PASS(MOD_A, true); else MNT753_PART_PASS(MOD_B, true);
+    if (frm == MOD_A) MNT753_PART_PASS(MOD_A, false); else MNT753_PART_PASS(MOD_B, false);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, part_cursor, n_parts);
+    if (frm == MOD_A) MNT753_PART_PASS(MOD_A, true); else MNT753_PART_PASS(MOD_B, true);
 #undef MNT753_PART_PASS
+  }
   const unsigned gc = (unsigned)((total + SORT_CHUNK - 1) / SORT_CHUNK);   // worst case: every digit non-zero
   hipLaunchKernelGGL((k_bucket_pass<false>), dim3(gc), dim3(1024), 0, st, keys_out, vals_out, part_start, n_parts, d_hist, d_offsets, d_sorted, pshift);
   const unsigned nsb = (unsigned)(((size_t)p.n_buckets + SCAN_BLOCK - 1) / SCAN_BLOCK);

@@ -40,11 +40,13 @@ def test_vs_oracle_seeded(gpu, curve, group, n):
     assert np.array_equal(gpu_msm_affine(gpu, curve, group, pts, sc), O.msm(curve, group, pts, sc, chunks=3))
 
 
-@pytest.mark.parametrize("sort", ["atomic", "part"])
+@pytest.mark.parametrize("sort", ["atomic", "part", "generic"])
 @pytest.mark.parametrize("curve,group", GROUPS)
 def test_edge_cases(gpu, curve, group, sort, monkeypatch):
     """Both sort stages (the counting sort with atomics that small inputs take by default, the hand-written two-level counting sort
-    forced onto this small input): empty list, no entries at all, one giant bucket per window, offsets."""
+    forced onto this small input -- "part": its partition passes with the window width as a template parameter where one is
+    instantiated, "generic": the kernels that read the width at run time): empty list, no entries at all, one giant bucket per
+    window, offsets."""
     monkeypatch.setenv("MNT753_MSM_SORT", sort)
     n = 96
     pts = gpu.synth_points(curve, group, 31, n)
@@ -102,6 +104,31 @@ def test_window_table_mode_small(gpu, curve, group, monkeypatch):
     assert np.array_equal(gpu.point_to_affine(curve, group, bs2.msm(sc)), got)
     assert not gpu.msm_last_plan()["window_table"]
     bs.close(); bs2.close()
+
+
+@pytest.mark.parametrize("bits", list(range(12, 23)))
+@pytest.mark.parametrize("curve", [0, 1])
+def test_partition_sort_at_every_window_width(gpu, curve, bits, monkeypatch):
+    """csrc/msm_sort.hip instantiates its partition passes per window width (k_part_pass_c<FRM, C, .>, C = 14 .. 22: digits from
+    registers, one staged word per entry) and keeps the kernels that read the width at run time for every other one (12 and 13 here).
+    Every instantiation, both scalar fields, on a set with zero / one / repeated scalars and identity / repeated bases, against the
+    oracle; and the run-time kernels on the same widths must agree."""
+    monkeypatch.setenv("MNT753_MSM_PRECOMP", "1")
+    monkeypatch.setenv("MNT753_MSM_TABLE_BITS", str(bits))
+    monkeypatch.setenv("MNT753_MSM_SORT", "part")
+    n = 150
+    pts = gpu.synth_points(curve, 1, 171 + bits, n); sc = gpu.synth_scalars(curve, 172 + bits, n)
+    pts[0] = 0; pts[n - 1] = 0; pts[10] = pts[11]; sc[10] = sc[11]; sc[3] = 0; sc[4] = gpu.api.mont_one(curve); sc[20:40] = sc[20]
+    expect = O.msm(curve, 1, pts, sc)
+    bs = gpu.BaseSet(curve, 1, pts)
+    got = gpu.point_to_affine(curve, 1, bs.msm(sc))
+    plan = gpu.msm_last_plan()
+    assert plan["window_table"] and plan["window_bits"] == bits
+    assert np.array_equal(got, expect)
+    assert np.array_equal(gpu.point_to_affine(curve, 1, bs.msm(sc[5:90], base_offset=20)), O.msm(curve, 1, pts[20:105], sc[5:90]))
+    monkeypatch.setenv("MNT753_MSM_SORT", "generic")
+    assert np.array_equal(gpu.point_to_affine(curve, 1, bs.msm(sc)), expect)
+    bs.close()
 
 
 def test_scalars_on_device_and_reuse(gpu):
@@ -476,7 +503,7 @@ def test_pairing_pass_cancellations_every_group(gpu, curve, group, irr, monkeypa
     assert not got.any()
 
 
-@pytest.mark.parametrize("sort,irr", [("part", None), ("part", "3")])
+@pytest.mark.parametrize("sort,irr", [("part", None), ("part", "3"), ("generic", None)])
 @pytest.mark.parametrize("group,logn", [(1, 19), (2, 17)])
 def test_skewed_scalars_with_the_pairing_pass(gpu, group, logn, sort, irr, monkeypatch):
     """The device-wide sort stage (the hand-written two-level counting sort).  The same three skewed scalar vectors at sizes where the pairing pass runs by default (G1 2^19, G2 2^17): a handful of
@@ -531,7 +558,7 @@ def test_randomized_configurations_vs_oracle(gpu, seed, monkeypatch):
     curve, group = GROUPS[int(rng.integers(0, 4))]
     n = int(rng.integers(1, 420 if group == 1 else 130))
     env = {"MNT753_MSM_PRECOMP": str(int(rng.integers(0, 2))), "MNT753_MSM_PAIR": str(int(rng.integers(0, 4))),
-           "MNT753_MSM_SORT": str(rng.choice(["atomic", "part"])), "MNT753_EDGE_FLOW_NODES": str(int(rng.choice([0, 4, 100000000]))),
+           "MNT753_MSM_SORT": str(rng.choice(["atomic", "part", "generic"])), "MNT753_EDGE_FLOW_NODES": str(int(rng.choice([0, 4, 100000000]))),
            "MNT753_MSM_TMIN": str(int(rng.choice([1, 2, 8]))), "MNT753_MSM_IRR": str(int(rng.integers(0, 4)))}
     for k, v in env.items():
         monkeypatch.setenv(k, v)
