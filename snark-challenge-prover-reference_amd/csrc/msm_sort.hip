@@ -177,21 +177,31 @@ template <int FRM, int C, bool PLACE>
 __global__ void __launch_bounds__(256) k_part_pass_c(const uint32_t* __restrict__ scal_wire, const uint8_t* __restrict__ inf, size_t n,
                                                     uint32_t hist_stride, uint32_t entry_stride, uint32_t entry_base, uint32_t n_parts,
                                                     uint32_t* __restrict__ part_total, uint32_t* __restrict__ part_cursor,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ scal_int) {
   constexpr int W = (754 + C - 1) / C;
   static_assert(W < 64, "the staged word holds the window in six bits");
+  static_assert(W >= 24, "the integer scalars of the counting pass are parked in the sorted list's buffer: 24 words per scalar");
   extern __shared__ uint32_t part_lds[];
   uint32_t* hist = part_lds;                     // [n_parts]
   const int tid = threadIdx.x;
   const size_t i = (size_t)blockIdx.x * blockDim.x + tid;
+  // The counting pass converts the scalar (wire Montgomery form -> integer: one product by a constant, ~2000 of its ~2800 instructions)
+  // and parks the integer, zeroed for an identity base, where the sorted list will be written later; the placing pass reads it back.
   uint32_t s[24];
-  {
+  if constexpr (!PLACE) {
     uint32_t w[24];
     if (i < n) {
       load_wire24(w, scal_wire + i * 24);
       fp_wire_to_integer<FRM>(s, w);
     }
     if (i >= n || inf[i]) {
+#pragma unroll
+      for (int j = 0; j < 24; ++j) s[j] = 0;
+    }
+    if (i < n) store_wire24(scal_int + i * 24, s);
+  } else {
+    if (i < n) load_wire24(s, scal_int + i * 24);
+    else {
 #pragma unroll
       for (int j = 0; j < 24; ++j) s[j] = 0;
     }
@@ -316,9 +326,14 @@ __global__ void __launch_bounds__(1024) k_bucket_pass(const uint32_t* __restrict
     __syncthreads();
   }
 }
-// The placing pass of level 2 with its entries ordered by bucket in LDS first: chunks of 16384 pairs, so that a bucket receives ~16
-// consecutive entries (64 B) from one chunk instead of single 4-byte writes (k_bucket_pass<true>: 0.54 ms for 159 MB).
-constexpr uint32_t PLACE_CHUNK = 16384;
+// The placing pass of level 2 with its entries ordered by bucket in LDS first, so that a bucket receives a run of consecutive entries
+// from one chunk instead of single 4-byte writes (k_bucket_pass<true>: 0.54 ms for 159 MB).  Chunks of 8192 pairs (runs of ~8 entries,
+// 60 KB of LDS: two workgroups per CU) since round 6: 0.18 ms at 2^20 G1 points against 0.23 with 16384 (one workgroup per CU; runs of
+// ~16 entries did not pay for the lost overlap, profiles/r06/sort_stage_by_width.txt).
+#ifndef MNT753_PLACE_CHUNK
+#define MNT753_PLACE_CHUNK 8192
+#endif
+constexpr uint32_t PLACE_CHUNK = MNT753_PLACE_CHUNK;
 constexpr size_t PLACE_LDS = sizeof(uint32_t) * (3u * PART_BUCKETS + PLACE_CHUNK) + sizeof(uint16_t) * PLACE_CHUNK;
 __global__ void __launch_bounds__(1024) k_bucket_place_staged(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ part_start,
                                                              uint32_t n_parts, uint32_t* __restrict__ placed, const uint32_t* __restrict__ offsets,
@@ -342,7 +357,7 @@ __global__ void __launch_bounds__(1024) k_bucket_place_staged(const uint32_t* __
     const uint32_t s = max(ps, lo), e = min(pe, hi);
     if (s >= e) continue;
     const uint32_t b0 = p << PART_BITS;
-    // this thread's (at most PLACE_CHUNK / 1024 = 16) pairs, all loads in flight at once and each pair read once (round 6; before: keys
+    // this thread's (at most PLACE_CHUNK / 1024) pairs, all loads in flight at once and each pair read once (round 6; before: keys
     // read in the counting loop and again, with the values, in the ranking loop -- three exposed latencies per segment instead of one)
     uint32_t kb[PLACE_CHUNK / 1024], vv[PLACE_CHUNK / 1024];
 #pragma unroll
@@ -415,9 +430,9 @@ int msm_sort_partition(int frm, const uint32_t* d_scal, const uint8_t* d_inf, si
 #define MNT753_PART_PASS_C(FRM, C)                                                                                                              \
   {                                                                                                                                             \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_pass_c<FRM, C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_LIMIT)); \
-    hipLaunchKernelGGL((k_part_pass_c<FRM, C, false>), dim3(gb), dim3(256), lds_count, st, d_scal, d_inf, n, hs, entry_stride, entry_base, n_parts, part_total, part_cursor, keys_out, vals_out); \
+    hipLaunchKernelGGL((k_part_pass_c<FRM, C, false>), dim3(gb), dim3(256), lds_count, st, d_scal, d_inf, n, hs, entry_stride, entry_base, n_parts, part_total, part_cursor, keys_out, vals_out, d_sorted); \
     hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, part_cursor, n_parts);                                   \
-    hipLaunchKernelGGL((k_part_pass_c<FRM, C, true>), dim3(gb), dim3(256), lds_place, st, d_scal, d_inf, n, hs, entry_stride, entry_base, n_parts, part_total, part_cursor, keys_out, vals_out); \
+    hipLaunchKernelGGL((k_part_pass_c<FRM, C, true>), dim3(gb), dim3(256), lds_place, st, d_scal, d_inf, n, hs, entry_stride, entry_base, n_parts, part_total, part_cursor, keys_out, vals_out, d_sorted); \
   }
 #define MNT753_PART_PASS_W(C) case C: if (frm == MOD_A) MNT753_PART_PASS_C(MOD_A, C) else MNT753_PART_PASS_C(MOD_B, C) break;
     switch (p.c) {
