@@ -50,6 +50,14 @@ thread_local int t_cur_dev = 0;   // logical device the calling thread works on 
 
 int init_one(int logical, int phys) {
   HIP_TRY(hipSetDevice(phys));
+  // The host thread SPINS while it waits for an MSM (hipEventSynchronize): a blocking wait costs 0.1-0.25 ms of wake-up latency per
+  // MSM on the shared hosts of the GPU boxes (profiles/r06/sync_policy.txt: 22.32-22.53 ms per step spinning, 22.49-22.68 blocking),
+  // and which of the two the runtime picks by itself (hipDeviceScheduleAuto) depends on the box.  A prover has a core to spare for it;
+  // MNT753_SYNC_SPIN=0 leaves the choice to the runtime.  (Ignored without harm where the device is already active.)
+  {
+    const char* e = getenv("MNT753_SYNC_SPIN");
+    if (!e || atoi(e) != 0) { (void)hipSetDeviceFlags(hipDeviceScheduleSpin); (void)hipGetLastError(); }
+  }
   HIP_TRY(hipFree(nullptr));
   // Keep scratch resident.  The 512-register point-arithmetic kernels spill a few hundred bytes (G1 reduction kernels)
   // to a few KB (Fq2/Fq3) per lane; ROCr sizes a dispatch's scratch for every wave slot of the device, and a dispatch
